@@ -1,0 +1,670 @@
+// svsdf_api.hip -- C-ABI host layer (include/svsdf_c.h) over the gfx950 kernels.
+//
+// Mirrors, for this one path, the state and call order of the reference's
+// TrajOptimizer::costFunctionLmbmParallel (BEO:344-408) and
+// addSaftyPenaOnSweptVolumeParallelTrueSDF (BEO:774-869); see include/svsdf_c.h for the
+// per-entry-point citations.  No CPU fallback: without a HIP device every compute entry fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/svsdf_c.h"
+#include "svsdf_kernels.hpp"
+#include "svsdf_minco.hpp"
+
+using namespace svsdf;
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+struct svsdf_ctx {
+  svsdf_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ShapeParams sp{};
+  double *d_poly = nullptr;
+  std::string err;
+
+  // points: this rank's shard, Morton-sorted
+  size_t P = 0;
+  std::vector<long long> shard_idx;  // original index of shard element j
+  double *d_px = nullptr, *d_py = nullptr;
+
+  // trajectory
+  TrajDev *d_traj = nullptr;
+  double *d_in = nullptr;  // device staging: coeffs (18N) | T (N) | tk (K)
+  double *h_in = nullptr;  // pinned mirror
+  size_t in_cap = 0;       // doubles
+  Pose *d_pose = nullptr;
+  size_t pose_cap = 0;
+  double traj_duration = 0.0;
+  bool have_duration = false;
+  int N = 0, K = 0;
+
+  // per-point buffers
+  double *d_sdf = nullptr, *d_t = nullptr;
+  double *d_res_sdf = nullptr, *d_res_t = nullptr, *d_res_gx = nullptr, *d_res_gy = nullptr;
+  GsipState gs{};
+  int *d_counters = nullptr;              // [0] n_interior, [1] n_active, [2] nonfinite
+  unsigned long long *d_stats = nullptr;  // [0] solves, [1] evals, [2] layer-1 evals
+  double *d_block_partials = nullptr;
+  size_t block_partials_cap = 0;  // doubles
+  double *d_partial = nullptr;    // 19 * kMaxPieces + 1
+  double *h_partial = nullptr;    // pinned
+
+  // profiling
+  bool profile = true;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  svsdf_stats stats{};
+
+  // full-callback state (TrajOptimizer members BEO:44-60)
+  svsdf_host::MincoS3 minco;
+  std::vector<double> T, pgC, pgT, cm, gC, gradq, gradT, xlast;
+  double energy_cost = 0.0;
+  double costs3[3] = {0, 0, 0};
+};
+
+namespace {
+
+int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
+  g_last_error = msg;
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(svsdf_ctx *ctx, T **p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) count = 1;
+  HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
+  return SVSDF_OK;
+}
+
+const char *kShapeNames[SVSDF_SHAPE_COUNT] = {
+    "sdUnevenCapsule", "sdCutDisk", "sdTrapezoid", "sdRhombus", "star", "sdTunnel",
+    "sdHorseshoe", "sdHeart", "sdOrientedVesica", "sdRoundedCross", "sdRoundedX", "bigX",
+    "sdMoon", "sdPie", "sdPie2", "sdArc", "Polygon"};
+
+inline uint32_t part1by1(uint32_t x) {
+  x &= 0x0000ffff;
+  x = (x ^ (x << 8)) & 0x00ff00ff;
+  x = (x ^ (x << 4)) & 0x0f0f0f0f;
+  x = (x ^ (x << 2)) & 0x33333333;
+  x = (x ^ (x << 1)) & 0x55555555;
+  return x;
+}
+
+hipEvent_t next_event(svsdf_ctx *ctx) {
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    ctx->ev_pool.push_back(e);
+  }
+  return ctx->ev_pool[ctx->ev_used++];
+}
+
+// ---- kernel dispatch over the shape id ---------------------------------------------------------
+#define SVSDF_FOR_SHAPE(id, CALL)                       \
+  switch (id) {                                         \
+    case 0: CALL(0); break;   case 1: CALL(1); break;   \
+    case 2: CALL(2); break;   case 3: CALL(3); break;   \
+    case 4: CALL(4); break;   case 5: CALL(5); break;   \
+    case 6: CALL(6); break;   case 7: CALL(7); break;   \
+    case 8: CALL(8); break;   case 9: CALL(9); break;   \
+    case 10: CALL(10); break; case 11: CALL(11); break; \
+    case 12: CALL(12); break; case 13: CALL(13); break; \
+    case 14: CALL(14); break; case 15: CALL(15); break; \
+    default: CALL(16); break;                           \
+  }
+
+void launch_solve(svsdf_ctx *ctx, const double *qx, const double *qy, int n_inner, int n_outer,
+                  size_t stride, double *out_sdf, double *out_t) {
+  const long long total = (long long)n_inner * n_outer;
+  if (total <= 0) return;
+  const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
+  const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
+  if (ctx->profile) (void)hipEventRecord(next_event(ctx), ctx->stream);
+#define CALL(S)                                                                                  \
+  hipLaunchKernelGGL((k_solve<S>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_traj, d_tk,  \
+                     ctx->d_pose, ctx->sp, qx, qy, n_inner, n_outer, stride, out_sdf, out_t,     \
+                     ctx->d_stats)
+  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+  if (ctx->profile) (void)hipEventRecord(next_event(ctx), ctx->stream);
+  ctx->stats.solve_launches++;
+}
+
+void launch_classify(svsdf_ctx *ctx) {
+  const unsigned grid = (unsigned)((ctx->P + kBlock - 1) / kBlock);
+#define CALL(S)                                                                                   \
+  hipLaunchKernelGGL((k_classify<S>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_traj,      \
+                     ctx->sp, ctx->d_px, ctx->d_py, (int)ctx->P, ctx->d_sdf, ctx->d_t,            \
+                     ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->P, \
+                     ctx->d_counters)
+  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+}
+
+// Upload (coeffs, T), update traj_duration like SweptVolumeManager::updateTraj (SWM:376-385),
+// build the layer-1 time grid exactly like the reference's accumulating loop (SWM:567).
+int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 64]");
+  double td = 0.0;
+  for (int i = 0; i < N; ++i) td += T[i];  // Trajectory::getTotalDuration (TRJ:410-419)
+  if (!(td == td) || std::isinf(td)) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite duration");
+  if (td < 3 * 1e2 || !ctx->have_duration) {
+    ctx->traj_duration = td;
+    ctx->have_duration = true;
+  }
+  const double dur = ctx->traj_duration;
+  size_t K = 0;
+  for (double t = 0.0; t <= dur; t += 0.15) ++K;
+  const size_t need = 19 * (size_t)N + K;
+  if (need > ctx->in_cap) {
+    const size_t cap = need + 4096;
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    ctx->h_in = nullptr;
+    HIPCHK(hipHostMalloc((void **)&ctx->h_in, cap * sizeof(double), hipHostMallocDefault));
+    int rc = dev_alloc(ctx, &ctx->d_in, cap);
+    if (rc) return rc;
+    ctx->in_cap = cap;
+  }
+  if (K > ctx->pose_cap) {
+    int rc = dev_alloc(ctx, &ctx->d_pose, K + 1024);
+    if (rc) return rc;
+    ctx->pose_cap = K + 1024;
+  }
+  std::memcpy(ctx->h_in, coeffs, sizeof(double) * 18 * N);
+  std::memcpy(ctx->h_in + 18 * N, T, sizeof(double) * N);
+  {
+    double *tk = ctx->h_in + 19 * N;
+    size_t k = 0;
+    for (double t = 0.0; t <= dur; t += 0.15) tk[k++] = t;
+  }
+  for (size_t i = 0; i < 19 * (size_t)N; ++i)
+    if (!std::isfinite(ctx->h_in[i])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite trajectory input");
+  ctx->N = N;
+  ctx->K = (int)K;
+  HIPCHK(hipMemcpyAsync(ctx->d_in, ctx->h_in, need * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_in, ctx->d_in + 18 * N, N,
+                     dur, (int)K, ctx->d_in + 19 * N, ctx->d_traj, ctx->d_pose);
+  return SVSDF_OK;
+}
+
+// Device pipeline up to the per-point results of getTrueSDFofSweptVolume (res_* arrays).
+int run_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  if (ctx->P == 0) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->ev_used = 0;
+  ctx->stats = svsdf_stats{};
+  ctx->stats.points = ctx->P;
+  hipEvent_t e_begin = next_event(ctx);
+  (void)hipEventRecord(e_begin, ctx->stream);
+  int rc = upload_traj(ctx, N, coeffs, T);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(int), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  // main queries
+  launch_solve(ctx, ctx->d_px, ctx->d_py, (int)ctx->P, 1, ctx->P, ctx->d_sdf, ctx->d_t);
+  launch_classify(ctx);
+  int n_int = 0;
+  HIPCHK(hipMemcpyAsync(&n_int, ctx->d_counters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stats.interior_points = (unsigned long long)n_int;
+  // GSIP rounds (SWM:965-1009): at most 9
+  int n_active = n_int;
+  for (int round = 0; round < 9 && n_active > 0; ++round) {
+    launch_solve(ctx, ctx->gs.sqx, ctx->gs.sqy, n_int, kMaxSlots, ctx->P, ctx->gs.sq_sdf, ctx->gs.sq_t);
+    HIPCHK(hipMemsetAsync(ctx->d_counters + 1, 0, sizeof(int), ctx->stream));
+    const unsigned grid = (unsigned)((n_int + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_gsip, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_px, ctx->d_py, ctx->gs,
+                       ctx->P, n_int, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
+                       ctx->d_counters + 1);
+    HIPCHK(hipMemcpyAsync(&n_active, ctx->d_counters + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return SVSDF_OK;
+}
+
+int finish_stats(svsdf_ctx *ctx, hipEvent_t e_end) {
+  unsigned long long st[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+  ctx->stats.solves = st[0];
+  ctx->stats.sdf_evals = st[1];
+  ctx->stats.scan_evals = st[2];
+  if (ctx->profile && ctx->ev_used >= 2) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], e_end);
+    ctx->stats.device_ms = ms;
+    double sum = 0.0;
+    // events: [0] begin, then (start, stop) pairs per solve launch, last = end
+    for (size_t i = 1; i + 1 < ctx->ev_used - 1; i += 2) {
+      float m = 0.f;
+      if (hipEventElapsedTime(&m, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess) sum += m;
+    }
+    ctx->stats.solve_ms = sum;
+  }
+  return SVSDF_OK;
+}
+
+// Whole device pipeline; leaves [cost, gradC, gradT] (19N+1 doubles) in ctx->d_partial.
+int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  int rc = run_queries(ctx, N, coeffs, T);
+  if (rc) return rc;
+  const unsigned grid = (unsigned)((ctx->P + kBlock - 1) / kBlock);
+  const size_t plen = 19 * (size_t)N + 1;
+  if ((size_t)grid * plen > ctx->block_partials_cap) {
+    rc = dev_alloc(ctx, &ctx->d_block_partials, (size_t)grid * plen);
+    if (rc) return rc;
+    ctx->block_partials_cap = (size_t)grid * plen;
+  }
+  hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_traj, ctx->d_px,
+                     ctx->d_py, (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
+                     ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_counters + 2);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_block_partials, (int)grid, N,
+                     ctx->d_partial);
+  hipEvent_t e_end = next_event(ctx);
+  (void)hipEventRecord(e_end, ctx->stream);
+  int nonfinite = 0;
+  HIPCHK(hipMemcpyAsync(&nonfinite, ctx->d_counters + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  rc = finish_stats(ctx, e_end);
+  if (rc) return rc;
+  if (nonfinite) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
+  return SVSDF_OK;
+}
+
+void accumulate(int N, const double *partial, double *cost, double *gradT, double *gradC) {
+  *cost += partial[0];
+  for (int e = 0; e < 18 * N; ++e) gradC[e] += partial[1 + e];
+  for (int j = 0; j < N; ++j) gradT[j] += partial[1 + 18 * N + j];
+}
+
+int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
+  int rc = 0;
+  if ((rc = dev_alloc(ctx, &ctx->d_px, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_py, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_sdf, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_t, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_res_sdf, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_res_t, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_res_gx, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_res_gy, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.pt, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.r, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.theta0, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.theta_res, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.iter, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.nsamp, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.done, P))) return rc;
+  const size_t S = P * kMaxSlots;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sqx, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sqy, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sqth, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sq_sdf, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sq_t, S))) return rc;
+  return SVSDF_OK;
+}
+
+int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
+  HIPCHK(hipSetDevice(ctx->device));
+  // Morton order so that the 64 lanes of a wave hold spatially adjacent points (similar t*,
+  // similar iteration counts, same interior/exterior class); the sum is order-independent.
+  std::vector<long long> order(P);
+  std::iota(order.begin(), order.end(), 0ll);
+  if (!(ctx->cfg.flags & SVSDF_FLAG_KEEP_INPUT_ORDER) && P > 1) {
+    double xmin = std::numeric_limits<double>::infinity(), xmax = -xmin, ymin = xmin, ymax = -xmin;
+    for (size_t i = 0; i < P; ++i) {
+      const double x = xyz[3 * i], y = xyz[3 * i + 1];
+      if (x < xmin) xmin = x; if (x > xmax) xmax = x;
+      if (y < ymin) ymin = y; if (y > ymax) ymax = y;
+    }
+    const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
+    std::vector<uint64_t> key(P);
+    for (size_t i = 0; i < P; ++i) {
+      const double fx = (xyz[3 * i] - xmin) / ext, fy = (xyz[3 * i + 1] - ymin) / ext;
+      const uint32_t qx = (uint32_t)std::min(65535.0, std::max(0.0, fx * 65535.0));
+      const uint32_t qy = (uint32_t)std::min(65535.0, std::max(0.0, fy * 65535.0));
+      key[i] = ((uint64_t)(part1by1(qx) | (part1by1(qy) << 1)) << 32) | (uint64_t)(i & 0xffffffffu);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](long long a, long long b) { return key[a] < key[b]; });
+  }
+  const int ws = std::max(1, ctx->cfg.world_size), rk = ctx->cfg.rank;
+  ctx->shard_idx.clear();
+  for (size_t k = (size_t)rk; k < P; k += (size_t)ws) ctx->shard_idx.push_back(order[k]);
+  const size_t Ps = ctx->shard_idx.size();
+  ctx->P = Ps;
+  int rc = alloc_point_buffers(ctx, Ps);
+  if (rc) return rc;
+  std::vector<double> hx(Ps), hy(Ps);
+  for (size_t j = 0; j < Ps; ++j) {
+    hx[j] = xyz[3 * ctx->shard_idx[j]];
+    hy[j] = xyz[3 * ctx->shard_idx[j] + 1];
+    if (!std::isfinite(hx[j]) || !std::isfinite(hy[j])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite query point");
+  }
+  HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
+  return SVSDF_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+void svsdf_config_default(svsdf_config *cfg) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->shape_id = SVSDF_SHAPE_star;
+  cfg->safety_hor = 0.7;  // src/plan_manager/config/star.yaml
+  cfg->weight_p = 60.0;
+  cfg->rho = 3.8;
+  cfg->device = -1;
+  cfg->rank = 0;
+  cfg->world_size = 1;
+}
+
+int svsdf_shape_id_from_inputdata(const char *inputdata) {
+  if (!inputdata) return SVSDF_SHAPE_Polygon;
+  std::string s(inputdata);
+  const size_t start = s.find_last_of('/') + 1;  // npos + 1 == 0
+  const size_t end = s.find_last_of('.');
+  const std::string stem = s.substr(start, end == std::string::npos ? std::string::npos : end - start);
+  for (int i = 0; i < SVSDF_SHAPE_Polygon; ++i)
+    if (stem == kShapeNames[i]) return i;
+  return SVSDF_SHAPE_Polygon;
+}
+
+const char *svsdf_shape_name(int id) { return (id >= 0 && id < SVSDF_SHAPE_COUNT) ? kShapeNames[id] : "?"; }
+
+const char *svsdf_last_error_string(const svsdf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
+  if (!cfg || cfg->shape_id < 0 || cfg->shape_id >= SVSDF_SHAPE_COUNT || cfg->world_size < 1 ||
+      cfg->rank < 0 || cfg->rank >= cfg->world_size) {
+    g_last_error = "svsdf_create: invalid config";
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_last_error = "svsdf_create: no HIP device (this library has no CPU fallback)";
+    return nullptr;
+  }
+  svsdf_ctx *ctx = new svsdf_ctx();
+  ctx->cfg = *cfg;
+  ctx->cfg.polygon_xy = nullptr;
+  int dev = cfg->device;
+  if (dev < 0) (void)hipGetDevice(&dev);
+  ctx->device = dev;
+  auto bail = [&](const std::string &m) -> svsdf_ctx * {
+    g_last_error = m;
+    svsdf_destroy(ctx);
+    return nullptr;
+  };
+  if (hipSetDevice(dev) != hipSuccess) return bail("hipSetDevice failed");
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  // shape constants, evaluated with the host libm exactly where the reference does (SHP:281-294,
+  // :855, :1237, :1278, :1320)
+  ShapeParams &sp = ctx->sp;
+  sp.tx = cfg->poly_params[0];
+  sp.ty = cfg->poly_params[1];
+  const double yaw = cfg->poly_params[2] * kPI / 180.0;
+  sp.r00 = std::cos(yaw); sp.r01 = -std::sin(yaw); sp.r10 = std::sin(yaw); sp.r11 = std::cos(yaw);
+  switch (cfg->shape_id) {
+    case SVSDF_SHAPE_sdHorseshoe: sp.c0x = std::cos(20.5); sp.c0y = std::sin(20.5); break;
+    case SVSDF_SHAPE_sdPie: sp.c0x = std::cos(43.0); sp.c0y = std::sin(43.0); break;
+    case SVSDF_SHAPE_sdPie2: sp.c0x = std::cos(1.0); sp.c0y = std::sin(1.0); break;
+    case SVSDF_SHAPE_sdArc: sp.c0x = std::sin(20.0); sp.c0y = std::cos(20.0); break;
+    default: sp.c0x = 0.0; sp.c0y = 0.0; break;
+  }
+  sp.r_bound = 0.0;
+  sp.nverts = 0;
+  sp.verts = nullptr;
+  if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
+    std::vector<double> v;
+    if (cfg->polygon_xy && cfg->polygon_nverts >= 3) {
+      const int n = std::min(cfg->polygon_nverts, SVSDF_MAX_POLY_VERTS);
+      v.assign(cfg->polygon_xy, cfg->polygon_xy + 2 * n);
+    } else {
+      v = {6, -0.1, 6, 0.1, -6, 0.1, -6, -0.1};  // SWM:363-369
+    }
+    if (hipMalloc((void **)&ctx->d_poly, v.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc polygon failed");
+    if (hipMemcpy(ctx->d_poly, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      return bail("hipMemcpy polygon failed");
+    sp.nverts = (int)(v.size() / 2);
+    sp.verts = ctx->d_poly;
+    ctx->cfg.polygon_nverts = sp.nverts;
+  }
+  if (hipMalloc((void **)&ctx->d_traj, sizeof(TrajDev)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_counters, 4 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_stats, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_partial, (19 * kMaxPieces + 1) * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_partial, (19 * kMaxPieces + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    return bail("device allocation failed");
+  return ctx;
+}
+
+void svsdf_destroy(svsdf_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void *bufs[] = {ctx->d_poly, ctx->d_px, ctx->d_py, ctx->d_traj, ctx->d_in, ctx->d_pose, ctx->d_sdf,
+                  ctx->d_t, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs.pt,
+                  ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp,
+                  ctx->gs.done, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth, ctx->gs.sq_sdf, ctx->gs.sq_t,
+                  ctx->d_counters, ctx->d_stats, ctx->d_block_partials, ctx->d_partial};
+  for (void *p : bufs)
+    if (p) (void)hipFree(p);
+  if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+  if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P) {
+  if (!ctx || (!xyz_aos && P)) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_points: null argument");
+  return set_points_host(ctx, xyz_aos, P);
+}
+
+int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P) {
+  if (!ctx || (!d_xyz_aos && P)) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_points_device: null argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<double> h(3 * P);
+  HIPCHK(hipMemcpy(h.data(), d_xyz_aos, 3 * P * sizeof(double), hipMemcpyDeviceToHost));
+  return set_points_host(ctx, h.data(), P);
+}
+
+size_t svsdf_num_points(const svsdf_ctx *ctx) { return ctx ? ctx->P : 0; }
+
+int svsdf_shard_indices(const svsdf_ctx *ctx, long long *idx_out) {
+  if (!ctx || !idx_out) return SVSDF_ERR_INVALID;
+  std::copy(ctx->shard_idx.begin(), ctx->shard_idx.end(), idx_out);
+  return SVSDF_OK;
+}
+
+int svsdf_eval_penalty_partial(svsdf_ctx *ctx, int N, const double *coeffs, const double *T,
+                               double **d_partial, size_t *partial_len) {
+  if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_eval_penalty_partial: null argument");
+  int rc = run_pipeline(ctx, N, coeffs, T);
+  if (rc) return rc;
+  if (d_partial) *d_partial = ctx->d_partial;
+  if (partial_len) *partial_len = 19 * (size_t)N + 1;
+  return SVSDF_OK;
+}
+
+int svsdf_accumulate_partial(svsdf_ctx *ctx, int N, const double *partial_host, double *cost,
+                             double *gradT, double *gradC) {
+  if (!ctx || !partial_host || !cost || !gradT || !gradC || N < 1 || N > kMaxPieces)
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_accumulate_partial: invalid argument");
+  for (int e = 0; e < 19 * N + 1; ++e)
+    if (!std::isfinite(partial_host[e])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite partial");
+  accumulate(N, partial_host, cost, gradT, gradC);
+  return SVSDF_OK;
+}
+
+int svsdf_eval_penalty(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *cost,
+                       double *gradT, double *gradC) {
+  if (!ctx || !coeffs || !T || !cost || !gradT || !gradC)
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_eval_penalty: null argument");
+  int rc = run_pipeline(ctx, N, coeffs, T);
+  if (rc) return rc;
+  const size_t plen = 19 * (size_t)N + 1;
+  HIPCHK(hipMemcpy(ctx->h_partial, ctx->d_partial, plen * sizeof(double), hipMemcpyDeviceToHost));
+  return svsdf_accumulate_partial(ctx, N, ctx->h_partial, cost, gradT, gradC);
+}
+
+int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *sdf,
+                       double *tstar, double *grad_xy) {
+  if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_query_points: null argument");
+  int rc = run_queries(ctx, N, coeffs, T);
+  if (rc) return rc;
+  hipEvent_t e_end = next_event(ctx);
+  (void)hipEventRecord(e_end, ctx->stream);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rc = finish_stats(ctx, e_end);
+  if (rc) return rc;
+  const size_t P = ctx->P;
+  if (sdf) HIPCHK(hipMemcpy(sdf, ctx->d_res_sdf, P * sizeof(double), hipMemcpyDeviceToHost));
+  if (tstar) HIPCHK(hipMemcpy(tstar, ctx->d_res_t, P * sizeof(double), hipMemcpyDeviceToHost));
+  if (grad_xy) {
+    std::vector<double> gx(P), gy(P);
+    HIPCHK(hipMemcpy(gx.data(), ctx->d_res_gx, P * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gy.data(), ctx->d_res_gy, P * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t j = 0; j < P; ++j) { grad_xy[2 * j] = gx[j]; grad_xy[2 * j + 1] = gy[j]; }
+  }
+  return SVSDF_OK;
+}
+
+int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out) {
+  if (!ctx || !out) return SVSDF_ERR_INVALID;
+  *out = ctx->stats;
+  return SVSDF_OK;
+}
+
+// ---- host MINCO helpers --------------------------------------------------------------------------
+int svsdf_minco_coeffs(const double head_state[9], const double tail_state[9], int N, const double *inPs,
+                       const double *T, double *coeffs) {
+  if (!head_state || !tail_state || !T || !coeffs || N < 1 || (N > 1 && !inPs)) return SVSDF_ERR_INVALID;
+  svsdf_host::MincoS3 m;
+  m.set_conditions(head_state, tail_state, N);
+  m.set_parameters(inPs, T);
+  m.coeffs_colmajor(coeffs);
+  return SVSDF_OK;
+}
+
+void svsdf_forward_T(const double *tau, double *T, int N) {
+  for (int i = 0; i < N; ++i) T[i] = svsdf_host::tau_to_T(tau[i]);
+}
+void svsdf_backward_T(const double *T, double *tau, int N) {
+  for (int i = 0; i < N; ++i) tau[i] = svsdf_host::T_to_tau(T[i]);
+}
+
+// ---- full optimizer callback (BEO:344-408) -------------------------------------------------------
+static int lmbm_prepare(svsdf_ctx *ctx, const double *x, int n) {
+  if (!ctx || !x || n < 1 || (n + 3) % 4 != 0) return fail(ctx, SVSDF_ERR_INVALID, "n must be 4N - 3");
+  const int N = (n + 3) / 4;
+  if (N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N > 64");
+  ctx->xlast.assign(x, x + n);
+  ctx->T.resize(N);
+  for (int i = 0; i < N; ++i) ctx->T[i] = svsdf_host::tau_to_T(x[i]);  // forwardT
+  ctx->minco.set_conditions(ctx->cfg.head_state, ctx->cfg.tail_state, N);
+  ctx->minco.set_parameters(x + N, ctx->T.data());                      // forwardP is a reshape
+  ctx->energy_cost = ctx->minco.energy();
+  ctx->pgC.resize(18 * (size_t)N);
+  ctx->pgT.resize(N);
+  ctx->minco.energy_grad_coeffs(ctx->pgC.data());
+  ctx->minco.energy_grad_times(ctx->pgT.data());
+  ctx->cm.resize(18 * (size_t)N);
+  ctx->minco.coeffs_colmajor(ctx->cm.data());
+  return SVSDF_OK;
+}
+
+static double lmbm_complete(svsdf_ctx *ctx, const double *partial, const double *x, double *g, int n) {
+  const int N = (n + 3) / 4;
+  double cost = ctx->energy_cost;
+  ctx->gC.assign(18 * (size_t)N, 0.0);
+  for (int r = 0; r < 6 * N; ++r)
+    for (int c = 0; c < 3; ++c) ctx->gC[(size_t)c * 6 * N + r] = ctx->pgC[r * 3 + c];
+  accumulate(N, partial, &cost, ctx->pgT.data(), ctx->gC.data());
+  for (int r = 0; r < 6 * N; ++r)
+    for (int c = 0; c < 3; ++c) ctx->pgC[r * 3 + c] = ctx->gC[(size_t)c * 6 * N + r];
+  const double pos_cost = cost - ctx->energy_cost;
+  ctx->gradq.assign(3 * (size_t)std::max(1, N - 1), 0.0);
+  ctx->gradT.assign(N, 0.0);
+  ctx->minco.propagate(ctx->pgC.data(), ctx->pgT.data(), ctx->gradq.data(), ctx->gradT.data());
+  double tsum = 0.0;
+  for (int i = 0; i < N; ++i) tsum += ctx->T[i];
+  cost += ctx->cfg.rho * tsum;
+  ctx->costs3[0] = pos_cost;
+  ctx->costs3[1] = cost - pos_cost;
+  ctx->costs3[2] = cost;
+  for (int i = 0; i < N; ++i) g[i] = svsdf_host::grad_T_to_tau(x[i], ctx->gradT[i] + ctx->cfg.rho);
+  for (int i = 0; i + 1 < N; ++i)
+    for (int c = 0; c < 3; ++c) g[N + 3 * i + c] = ctx->gradq[i * 3 + c];
+  return cost;
+}
+
+int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial, size_t *partial_len) {
+  int rc = lmbm_prepare(ctx, x, n);
+  if (rc) return rc;
+  const int N = (n + 3) / 4;
+  return svsdf_eval_penalty_partial(ctx, N, ctx->cm.data(), ctx->T.data(), d_partial, partial_len);
+}
+
+// Uses the x given to the matching svsdf_lmbm_begin; the caller passes the same n.
+double svsdf_lmbm_finish(svsdf_ctx *ctx, const double *partial_host, double *g, int n) {
+  if (!ctx || !partial_host || !g || (int)ctx->xlast.size() != n) return std::numeric_limits<double>::infinity();
+  const int N = (n + 3) / 4;
+  const std::vector<double> &x = ctx->xlast;
+  for (int e = 0; e < 19 * N + 1; ++e)
+    if (!std::isfinite(partial_host[e])) {
+      std::fill(g, g + n, 0.0);
+      fail(ctx, SVSDF_ERR_NONFINITE, "non-finite partial");
+      return std::numeric_limits<double>::infinity();
+    }
+  return lmbm_complete(ctx, partial_host, x.data(), g, n);
+}
+
+double svsdf_lmbm_evaluate(void *vctx, const double *x, double *g, const int n) {
+  svsdf_ctx *ctx = (svsdf_ctx *)vctx;
+  const double inf = std::numeric_limits<double>::infinity();
+  if (g && n > 0) std::fill(g, g + n, 0.0);
+  if (!ctx || !x || !g) return inf;
+  if (lmbm_prepare(ctx, x, n)) return inf;
+  const int N = (n + 3) / 4;
+  if (run_pipeline(ctx, N, ctx->cm.data(), ctx->T.data())) return inf;
+  const size_t plen = 19 * (size_t)N + 1;
+  if (hipMemcpy(ctx->h_partial, ctx->d_partial, plen * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return inf;
+  for (size_t e = 0; e < plen; ++e)
+    if (!std::isfinite(ctx->h_partial[e])) return inf;
+  return lmbm_complete(ctx, ctx->h_partial, x, g, n);
+}
+
+int svsdf_last_costs(const svsdf_ctx *ctx, double costs3[3]) {
+  if (!ctx || !costs3) return SVSDF_ERR_INVALID;
+  costs3[0] = ctx->costs3[0]; costs3[1] = ctx->costs3[1]; costs3[2] = ctx->costs3[2];
+  return SVSDF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,14 @@
+"""svsdf_amd -- Python host mirror of the reference's TrajOptimizer interface for the SVSDF
+safety cost/gradient path, on top of the C ABI (include/svsdf_c.h) of the gfx950 library.
+
+PyTorch is used only for device memory and torch.distributed (RCCL) plumbing; the compute is
+in csrc/ (hand-written HIP).  There is no CPU fallback: every compute call raises if the HIP
+library or a GPU is missing.
+"""
+from .binding import (SHAPES, SHAPE_ID, SvsdfError, SvsdfContext, lib, lib_path, minco_coeffs,
+                      forward_T, backward_T, shape_id_from_inputdata)
+from .traj_optimizer import TrajOptimizer
+from . import workload
+
+__all__ = ["SHAPES", "SHAPE_ID", "SvsdfError", "SvsdfContext", "TrajOptimizer", "lib", "lib_path",
+           "minco_coeffs", "forward_T", "backward_T", "shape_id_from_inputdata", "workload"]

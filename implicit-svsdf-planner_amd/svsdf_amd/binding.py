@@ -1,0 +1,272 @@
+"""ctypes binding of libsvsdf_hip.so (C ABI declared in include/svsdf_c.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+SHAPES = ["sdUnevenCapsule", "sdCutDisk", "sdTrapezoid", "sdRhombus", "star", "sdTunnel",
+          "sdHorseshoe", "sdHeart", "sdOrientedVesica", "sdRoundedCross", "sdRoundedX", "bigX",
+          "sdMoon", "sdPie", "sdPie2", "sdArc", "Polygon"]
+SHAPE_ID = {n: i for i, n in enumerate(SHAPES)}
+
+_dp = C.POINTER(C.c_double)
+
+# every symbol include/svsdf_c.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "svsdf_create", "svsdf_destroy", "svsdf_config_default", "svsdf_shape_id_from_inputdata",
+    "svsdf_shape_name", "svsdf_last_error_string", "svsdf_set_points", "svsdf_set_points_device",
+    "svsdf_num_points", "svsdf_eval_penalty", "svsdf_eval_penalty_partial",
+    "svsdf_accumulate_partial", "svsdf_lmbm_evaluate", "svsdf_last_costs", "svsdf_lmbm_begin",
+    "svsdf_lmbm_finish", "svsdf_minco_coeffs", "svsdf_forward_T", "svsdf_backward_T",
+    "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("shape_id", C.c_int), ("poly_params", C.c_double * 3), ("safety_hor", C.c_double),
+                ("weight_p", C.c_double), ("rho", C.c_double), ("head_state", C.c_double * 9),
+                ("tail_state", C.c_double * 9), ("device", C.c_int), ("polygon_nverts", C.c_int),
+                ("polygon_xy", _dp), ("rank", C.c_int), ("world_size", C.c_int), ("flags", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("points", C.c_ulonglong), ("interior_points", C.c_ulonglong),
+                ("solves", C.c_ulonglong), ("sdf_evals", C.c_ulonglong),
+                ("scan_evals", C.c_ulonglong), ("device_ms", C.c_double), ("solve_ms", C.c_double),
+                ("solve_launches", C.c_uint)]
+
+
+class SvsdfError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_PKG, "libsvsdf_hip.so")
+
+
+def lib():
+    """Load the HIP library.  Raises if it has not been built: there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SvsdfError(f"{path} is missing: run `python __graft_entry__.py build` "
+                         "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+    L = C.CDLL(path)
+    L.svsdf_create.restype = C.c_void_p
+    L.svsdf_create.argtypes = [C.POINTER(Config)]
+    L.svsdf_destroy.argtypes = [C.c_void_p]
+    L.svsdf_config_default.argtypes = [C.POINTER(Config)]
+    L.svsdf_shape_id_from_inputdata.restype = C.c_int
+    L.svsdf_shape_id_from_inputdata.argtypes = [C.c_char_p]
+    L.svsdf_shape_name.restype = C.c_char_p
+    L.svsdf_shape_name.argtypes = [C.c_int]
+    L.svsdf_last_error_string.restype = C.c_char_p
+    L.svsdf_last_error_string.argtypes = [C.c_void_p]
+    L.svsdf_set_points.argtypes = [C.c_void_p, _dp, C.c_size_t]
+    L.svsdf_set_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.svsdf_num_points.restype = C.c_size_t
+    L.svsdf_num_points.argtypes = [C.c_void_p]
+    L.svsdf_eval_penalty.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    L.svsdf_eval_penalty_partial.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_size_t)]
+    L.svsdf_accumulate_partial.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
+    L.svsdf_lmbm_evaluate.restype = C.c_double
+    L.svsdf_lmbm_evaluate.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+    L.svsdf_last_costs.argtypes = [C.c_void_p, _dp]
+    L.svsdf_lmbm_begin.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.svsdf_lmbm_finish.restype = C.c_double
+    L.svsdf_lmbm_finish.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+    L.svsdf_minco_coeffs.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _dp]
+    L.svsdf_forward_T.argtypes = [_dp, _dp, C.c_int]
+    L.svsdf_backward_T.argtypes = [_dp, _dp, C.c_int]
+    L.svsdf_query_points.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    L.svsdf_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.svsdf_shard_indices.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    _LIB = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _colmajor(m):
+    """(rows, cols) array -> flat column-major copy (Eigen's default storage)."""
+    return np.asfortranarray(_f64(m)).ravel(order="F").copy()
+
+
+def shape_id_from_inputdata(inputdata):
+    return lib().svsdf_shape_id_from_inputdata(inputdata.encode())
+
+
+def minco_coeffs(head_state, tail_state, inPs, T):
+    """(3x3 head, 3x3 tail, (N-1, 3) waypoints, (N,) durations) -> (6N, 3) coefficients
+    (row 6i+k = coefficient of s^k of piece i), via the product's host MINCO."""
+    T = _f64(T)
+    N = len(T)
+    q = _f64(inPs).reshape(-1, 3).copy()
+    out = np.zeros(18 * N)
+    rc = lib().svsdf_minco_coeffs(_p(_colmajor(head_state)), _p(_colmajor(tail_state)), N, _p(q), _p(T), _p(out))
+    if rc:
+        raise SvsdfError(f"svsdf_minco_coeffs failed: {rc}")
+    return out.reshape(3, 6 * N).T.copy()
+
+
+def forward_T(tau):
+    tau = _f64(tau)
+    T = np.zeros_like(tau)
+    lib().svsdf_forward_T(_p(tau), _p(T), len(tau))
+    return T
+
+
+def backward_T(T):
+    T = _f64(T)
+    tau = np.zeros_like(T)
+    lib().svsdf_backward_T(_p(T), _p(tau), len(T))
+    return tau
+
+
+class SvsdfContext:
+    """Owns one svsdf_ctx (one GPU, one shard of the query points)."""
+
+    def __init__(self, shape="star", safety_hor=0.7, weight_p=60.0, rho=3.8,
+                 poly_params=(0.0, 0.0, 0.0), polygon=None, head_state=None, tail_state=None,
+                 device=-1, rank=0, world_size=1, flags=0):
+        self.L = lib()
+        cfg = Config()
+        self.L.svsdf_config_default(C.byref(cfg))
+        cfg.shape_id = SHAPE_ID[shape] if isinstance(shape, str) else int(shape)
+        cfg.poly_params[:] = list(map(float, poly_params))
+        cfg.safety_hor, cfg.weight_p, cfg.rho = float(safety_hor), float(weight_p), float(rho)
+        hs = np.zeros((3, 3)) if head_state is None else _f64(head_state)
+        ts = np.zeros((3, 3)) if tail_state is None else _f64(tail_state)
+        cfg.head_state[:] = list(_colmajor(hs))
+        cfg.tail_state[:] = list(_colmajor(ts))
+        cfg.device, cfg.rank, cfg.world_size, cfg.flags = int(device), int(rank), int(world_size), int(flags)
+        self._poly = None
+        if polygon is not None:
+            self._poly = _f64(polygon).reshape(-1, 2).copy()
+            cfg.polygon_nverts = len(self._poly)
+            cfg.polygon_xy = _p(self._poly)
+        h = self.L.svsdf_create(C.byref(cfg))
+        if not h:
+            raise SvsdfError("svsdf_create failed: " + self.L.svsdf_last_error_string(None).decode())
+        self.ctx = C.c_void_p(h)
+        self.head_state, self.tail_state = hs, ts
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.svsdf_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise SvsdfError(f"{what} failed ({rc}): " + self.L.svsdf_last_error_string(self.ctx).decode())
+
+    # ---- points ----
+    def set_points(self, xyz):
+        xyz = _f64(xyz).reshape(-1, 3)
+        self._chk(self.L.svsdf_set_points(self.ctx, _p(xyz), len(xyz)), "svsdf_set_points")
+
+    def set_points_device(self, dev_ptr, P):
+        self._chk(self.L.svsdf_set_points_device(self.ctx, C.c_void_p(int(dev_ptr)), int(P)), "svsdf_set_points_device")
+
+    def num_points(self):
+        return int(self.L.svsdf_num_points(self.ctx))
+
+    def shard_indices(self):
+        idx = np.zeros(self.num_points(), dtype=np.int64)
+        if len(idx):
+            self._chk(self.L.svsdf_shard_indices(self.ctx, idx.ctypes.data_as(C.POINTER(C.c_longlong))), "svsdf_shard_indices")
+        return idx
+
+    # ---- inner operator ----
+    def eval_penalty(self, coeffs, T, cost0=0.0, gradT0=None, gradC0=None):
+        """coeffs (6N, 3), T (N,) -> (cost, gradT (N,), gradC (6N, 3)); accumulates like BEO:774-869."""
+        T = _f64(T)
+        N = len(T)
+        cm = _colmajor(coeffs)
+        cost = C.c_double(cost0)
+        gT = np.zeros(N) if gradT0 is None else _f64(gradT0).copy()
+        gC = np.zeros(18 * N) if gradC0 is None else _colmajor(gradC0)
+        self._chk(self.L.svsdf_eval_penalty(self.ctx, N, _p(cm), _p(T), C.byref(cost), _p(gT), _p(gC)), "svsdf_eval_penalty")
+        return cost.value, gT, gC.reshape(3, 6 * N).T.copy()
+
+    def eval_penalty_partial(self, coeffs, T):
+        """Runs the device pipeline; returns (device pointer, length) of [cost, gradC, gradT]."""
+        T = _f64(T)
+        N = len(T)
+        cm = _colmajor(coeffs)
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.svsdf_eval_penalty_partial(self.ctx, N, _p(cm), _p(T), C.byref(ptr), C.byref(n)), "svsdf_eval_penalty_partial")
+        return ptr.value, n.value
+
+    def accumulate_partial(self, N, partial, cost0=0.0, gradT0=None, gradC0=None):
+        partial = _f64(partial)
+        cost = C.c_double(cost0)
+        gT = np.zeros(N) if gradT0 is None else _f64(gradT0).copy()
+        gC = np.zeros(18 * N) if gradC0 is None else _colmajor(gradC0)
+        self._chk(self.L.svsdf_accumulate_partial(self.ctx, N, _p(partial), C.byref(cost), _p(gT), _p(gC)), "svsdf_accumulate_partial")
+        return cost.value, gT, gC.reshape(3, 6 * N).T.copy()
+
+    # ---- full callback ----
+    def lmbm_evaluate(self, x):
+        x = _f64(x)
+        g = np.zeros_like(x)
+        f = self.L.svsdf_lmbm_evaluate(self.ctx, _p(x), _p(g), len(x))
+        if not np.isfinite(f):
+            raise SvsdfError("svsdf_lmbm_evaluate failed: " + self.L.svsdf_last_error_string(self.ctx).decode())
+        return f, g
+
+    def last_costs(self):
+        c = np.zeros(3)
+        self.L.svsdf_last_costs(self.ctx, _p(c))
+        return c
+
+    def lmbm_begin(self, x):
+        x = _f64(x)
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.svsdf_lmbm_begin(self.ctx, _p(x), len(x), C.byref(ptr), C.byref(n)), "svsdf_lmbm_begin")
+        return ptr.value, n.value
+
+    def lmbm_finish(self, partial, n):
+        partial = _f64(partial)
+        g = np.zeros(n)
+        f = self.L.svsdf_lmbm_finish(self.ctx, _p(partial), _p(g), n)
+        if not np.isfinite(f):
+            raise SvsdfError("svsdf_lmbm_finish failed: " + self.L.svsdf_last_error_string(self.ctx).decode())
+        return f, g
+
+    # ---- diagnostics ----
+    def query_points(self, coeffs, T):
+        """Per-point (sdf, t*, grad_xy) in the ORIGINAL order of the points given to set_points
+        (world_size == 1) or of this rank's shard (see shard_indices)."""
+        T = _f64(T)
+        N = len(T)
+        cm = _colmajor(coeffs)
+        P = self.num_points()
+        sdf, ts, g = np.zeros(P), np.zeros(P), np.zeros((P, 2))
+        self._chk(self.L.svsdf_query_points(self.ctx, N, _p(cm), _p(T), _p(sdf), _p(ts), _p(g)), "svsdf_query_points")
+        idx = self.shard_indices()
+        order = np.argsort(idx, kind="stable")
+        return sdf[order], ts[order], g[order], idx[order]
+
+    def stats(self):
+        s = Stats()
+        self.L.svsdf_last_stats(self.ctx, C.byref(s))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}

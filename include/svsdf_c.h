@@ -1,0 +1,174 @@
+/*
+ * svsdf_c.h -- C ABI of the MI355X-native SVSDF cost/gradient evaluator.
+ *
+ * Drop-in boundary for ONE hot path of ZJU-FAST-Lab/Implicit-SVSDF-Planner: the per-query-point
+ * swept-volume-SDF safety penalty and its gradient evaluated inside the back-end optimizer's
+ * cost callback.  Every entry point cites the reference interface it replaces; paths are
+ * relative to the reference root, with
+ *   BEO = src/planner_algorithm/include/planner_algorithm/back_end_optimizer.hpp
+ *   SWM = src/swept_volume/include/swept_volume/sw_manager.hpp
+ *   SHP = src/utils/include/utils/Shape.hpp
+ *   MNC = src/utils/include/utils/minco.hpp
+ *
+ * Plain pointers and sizes only; no Eigen / torch / HIP types.  All matrices are COLUMN-major
+ * exactly as the reference's Eigen objects store them.  One thread at a time per context (the
+ * reference's LMBM driver is single-threaded and non-reentrant: src/utils/src/lmbm.cpp:4-6).
+ *
+ * The library needs a gfx950 device: every compute entry point returns a non-zero error code
+ * (and svsdf_lmbm_evaluate returns +inf with g zeroed) when no HIP device is usable -- there is
+ * no CPU fallback.
+ */
+#ifndef SVSDF_C_H
+#define SVSDF_C_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Shape ids: registry order of SWM:187-235 (the reference keys the registry by the stem of
+ * conf.inputdata, SWM:352-355), then the fallback Polygon (SWM:363-372). */
+enum svsdf_shape_id {
+  SVSDF_SHAPE_sdUnevenCapsule = 0,
+  SVSDF_SHAPE_sdCutDisk = 1,
+  SVSDF_SHAPE_sdTrapezoid = 2,
+  SVSDF_SHAPE_sdRhombus = 3,
+  SVSDF_SHAPE_star = 4,
+  SVSDF_SHAPE_sdTunnel = 5,
+  SVSDF_SHAPE_sdHorseshoe = 6,
+  SVSDF_SHAPE_sdHeart = 7,
+  SVSDF_SHAPE_sdOrientedVesica = 8,
+  SVSDF_SHAPE_sdRoundedCross = 9,
+  SVSDF_SHAPE_sdRoundedX = 10,
+  SVSDF_SHAPE_bigX = 11,
+  SVSDF_SHAPE_sdMoon = 12,
+  SVSDF_SHAPE_sdPie = 13,
+  SVSDF_SHAPE_sdPie2 = 14,
+  SVSDF_SHAPE_sdArc = 15,
+  SVSDF_SHAPE_Polygon = 16,
+  SVSDF_SHAPE_COUNT = 17
+};
+
+#define SVSDF_MAX_PIECES 64        /* MINCO pieces per trajectory handled on the device */
+#define SVSDF_MAX_POLY_VERTS 256   /* Polygon outline vertices */
+
+/* Error codes (0 = ok).  HIP runtime errors are returned as SVSDF_ERR_HIP_BASE + hipError_t. */
+enum svsdf_status {
+  SVSDF_OK = 0,
+  SVSDF_ERR_INVALID = 1,       /* bad argument (null ctx, N out of range, n != 4N-3, ...) */
+  SVSDF_ERR_NO_DEVICE = 2,     /* no usable gfx950 device / HIP runtime unavailable */
+  SVSDF_ERR_NO_POINTS = 3,     /* evaluate called before svsdf_set_points */
+  SVSDF_ERR_NONFINITE = 4,     /* a non-finite value was produced on the device */
+  SVSDF_ERR_HIP_BASE = 1000
+};
+
+/* What the callee reads from TrajOptimizer / Config / SweptVolumeManager (BEO:50-95,
+ * src/utils/include/utils/config.hpp:13-224). */
+typedef struct svsdf_config {
+  int shape_id;              /* enum svsdf_shape_id; see svsdf_shape_id_from_inputdata() */
+  double poly_params[3];     /* Config::poly_params: shape offset x, y [m], yaw [deg]  SHP:281-294 */
+  double safety_hor;         /* TrajOptimizer::safety_hor                              BEO:83 */
+  double weight_p;           /* TrajOptimizer::weight_p                                BEO:77 */
+  double rho;                /* TrajOptimizer::rho (time weight)                       BEO:48 */
+  double head_state[9];      /* initState  3x3 col-major: col0 pos, col1 vel, col2 acc BEO:49 */
+  double tail_state[9];      /* finalState 3x3 col-major                               BEO:50 */
+  int device;                /* HIP device ordinal; -1 = current device */
+  int polygon_nverts;        /* Polygon only: outline vertices (0 -> the 12 x 0.2 fallback  */
+  const double *polygon_xy;  /*   rectangle of SWM:363-369); xy interleaved, copied         */
+  int rank, world_size;      /* point sharding: this context keeps points k with
+                                (sorted index k) % world_size == rank.  1 process per GPU. */
+  int flags;                 /* SVSDF_FLAG_* */
+} svsdf_config;
+
+#define SVSDF_FLAG_DEFAULT 0
+#define SVSDF_FLAG_KEEP_INPUT_ORDER 1 /* do not Morton-sort the cloud at upload (debug) */
+
+typedef struct svsdf_ctx svsdf_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* Replaces TrajOptimizer::setParam + SweptVolumeManager::init/initShape (SWM:339-374) for the
+ * state this path reads.  Returns NULL on failure (see svsdf_last_error_string). */
+svsdf_ctx *svsdf_create(const svsdf_config *cfg);
+void svsdf_destroy(svsdf_ctx *ctx);
+void svsdf_config_default(svsdf_config *cfg);
+/* shape registry lookup as SWM:350-356 does it: stem of "shapes/star.obj" -> "star" -> id;
+ * unknown stems give SVSDF_SHAPE_Polygon (the reference's fallback). */
+int svsdf_shape_id_from_inputdata(const char *inputdata);
+const char *svsdf_shape_name(int shape_id);
+const char *svsdf_last_error_string(const svsdf_ctx *ctx); /* ctx may be NULL */
+
+/* ---- query points -------------------------------------------------------------------------- */
+/* Replaces the fill of TrajOptimizer::parallel_points (src/plan_manager/src/plan_manager.cpp:
+ * 168-175): P points, AoS xyz doubles (Eigen::Vector3d layout); z is ignored (BEO:790-791).
+ * Copies; the cloud stays resident in HBM for all following evaluations. */
+int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P);
+/* Same, but xyz_aos is a DEVICE pointer on ctx's device (inputs already resident in HBM). */
+int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P);
+size_t svsdf_num_points(const svsdf_ctx *ctx);        /* points owned by this rank's shard */
+
+/* ---- the inner operator ---------------------------------------------------------------------- */
+/* Replaces TrajOptimizer::addSaftyPenaOnSweptVolumeParallelTrueSDF (BEO:774-869):
+ *   coeffs  : (6N) x 3 col-major, row 6i+k = coefficient of s^k of piece i (minco.getCoeffs())
+ *   T       : N piece durations
+ *   cost, gradT[N], gradC[(6N) x 3 col-major] are ACCUMULATED INTO (+=) like the reference.
+ * Also performs SweptVolumeManager::updateTraj (SWM:376-385). Synchronises before returning. */
+int svsdf_eval_penalty(svsdf_ctx *ctx, int N, const double *coeffs, const double *T,
+                       double *cost, double *gradT, double *gradC);
+
+/* Multi-process form (one process per GPU): leaves this rank's partial
+ *   [ cost, gradC (18N, col-major), gradT (N) ]  = 19N + 1 doubles
+ * in a device buffer owned by the context so the caller can all-reduce it in place (RCCL via
+ * torch.distributed / ncclAllReduce), then hand it back to svsdf_accumulate_partial. */
+int svsdf_eval_penalty_partial(svsdf_ctx *ctx, int N, const double *coeffs, const double *T,
+                               double **d_partial, size_t *partial_len);
+int svsdf_accumulate_partial(svsdf_ctx *ctx, int N, const double *partial_host,
+                             double *cost, double *gradT, double *gradC);
+
+/* ---- the full optimizer callback --------------------------------------------------------------- */
+/* Same signature as lmbm_evaluate_t (src/utils/include/utils/lmbm.h:206-209); replaces
+ * TrajOptimizer::costFunctionLmbmParallel (BEO:344-408) including MINCO forward/adjoint
+ * (MNC:433-654) and the tau/xi maps (BEO:174-314).  x = [tau_0..tau_{N-1}, q_0(x,y,yaw), ...,
+ * q_{N-2}], n = 4N - 3.  Returns the total cost and OVERWRITES g[0..n).  On a device error
+ * returns +infinity with g zeroed (the reference has no error channel here). */
+double svsdf_lmbm_evaluate(void *ctx, const double *x, double *g, const int n);
+/* cost_pos, cost_other, cost_total of the last svsdf_lmbm_evaluate (BEO:396-398). */
+int svsdf_last_costs(const svsdf_ctx *ctx, double costs3[3]);
+/* Full callback split around the collective for the one-process-per-GPU form:
+ * begin -> all-reduce the device partial -> finish. */
+int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial, size_t *partial_len);
+double svsdf_lmbm_finish(svsdf_ctx *ctx, const double *partial_host, double *g, int n);
+
+/* ---- host-side MINCO helpers (MNC:397-655) ------------------------------------------------------- */
+/* waypoints inPs: 3 x (N-1) col-major; out coeffs (6N) x 3 col-major. */
+int svsdf_minco_coeffs(const double head_state[9], const double tail_state[9], int N,
+                       const double *inPs, const double *T, double *coeffs);
+void svsdf_forward_T(const double *tau, double *T, int N);   /* BEO:213-226 */
+void svsdf_backward_T(const double *T, double *tau, int N);  /* BEO:228-241 */
+
+/* ---- diagnostics ------------------------------------------------------------------------------------ */
+/* Per-point results of getTrueSDFofSweptVolume<true> (SWM:916-1018) for the last trajectory
+ * given to this context, in the ORIGINAL input order of this rank's shard: sdf[P], tstar[P],
+ * grad_xy[2P] (any may be NULL).  Runs the device pipeline for (N, coeffs, T) first. */
+int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T,
+                       double *sdf, double *tstar, double *grad_xy);
+/* Work counters of the last evaluation. */
+typedef struct svsdf_stats {
+  unsigned long long points;          /* main queries in this shard */
+  unsigned long long interior_points; /* points that entered the GSIP loop */
+  unsigned long long solves;          /* argmin solves (main + GSIP sub-queries) */
+  unsigned long long sdf_evals;       /* SDF-at-time evaluations executed on the device */
+  unsigned long long scan_evals;      /* of which layer-1 table evaluations */
+  double device_ms;                   /* HIP-event time of the whole device pipeline */
+  double solve_ms;                    /* HIP-event time summed over the argmin (solve) kernels */
+  unsigned int solve_launches;
+} svsdf_stats;
+int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
+/* Original indices (into the array given to svsdf_set_points) of this rank's shard, in the
+ * order svsdf_query_points reports them. */
+int svsdf_shard_indices(const svsdf_ctx *ctx, long long *idx_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,149 @@
+/*
+ * svsdf_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's swept-volume-SDF safety cost + gradient
+ * path (ZJU-FAST-Lab/Implicit-SVSDF-Planner @ 2024_08_07), every function citing
+ * the reference file:line it follows.  Abbreviations used in the citations:
+ *   BEO = src/planner_algorithm/include/planner_algorithm/back_end_optimizer.hpp
+ *   SWM = src/swept_volume/include/swept_volume/sw_manager.hpp
+ *   SHP = src/utils/include/utils/Shape.hpp
+ *   TRJ = src/utils/include/utils/trajectory.hpp
+ *   MNC = src/utils/include/utils/minco.hpp
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors / known-answer tests for
+ * this path and cannot be built in this image (needs Eigen3, ROS noetic, PCL,
+ * gfortran, a missing libigl blob).  The restatement is pinned only by (i) the
+ * analytic anchors derivable from the cited formulas, (ii) the reference's own
+ * shape meshes (src/plan_manager/shapes/<name>.obj, whose vertices must lie on/in the
+ * zero level set of the matching SDF), (iii) an independently written pure-Python
+ * second restatement (tests/golden/make_golden.py) and (iv) finite-difference
+ * checks of the assembled gradient.  See DESIGN.md "Oracle".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this library.  The product path (implicit-svsdf-planner_amd/csrc) never links,
+ * loads or calls it.
+ */
+#ifndef SVSDF_ORACLE_H
+#define SVSDF_ORACLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Shape ids: registry order of SWM:187-235, then the fallback Polygon (SWM:363-372). */
+enum {
+  ORC_SHAPE_sdUnevenCapsule = 0,
+  ORC_SHAPE_sdCutDisk = 1,
+  ORC_SHAPE_sdTrapezoid = 2,
+  ORC_SHAPE_sdRhombus = 3,
+  ORC_SHAPE_star = 4,
+  ORC_SHAPE_sdTunnel = 5,
+  ORC_SHAPE_sdHorseshoe = 6,
+  ORC_SHAPE_sdHeart = 7,
+  ORC_SHAPE_sdOrientedVesica = 8,
+  ORC_SHAPE_sdRoundedCross = 9,
+  ORC_SHAPE_sdRoundedX = 10,
+  ORC_SHAPE_bigX = 11,
+  ORC_SHAPE_sdMoon = 12,
+  ORC_SHAPE_sdPie = 13,
+  ORC_SHAPE_sdPie2 = 14,
+  ORC_SHAPE_sdArc = 15,
+  ORC_SHAPE_Polygon = 16,
+  ORC_SHAPE_COUNT = 17
+};
+
+#define ORC_MAX_POLY_VERTS 256
+
+typedef struct orc_shape {
+  int id;
+  double tx, ty;          /* trans = (poly_params[0], poly_params[1])   SHP:281-294 */
+  double r00, r01, r10, r11; /* Rotate (yaw = poly_params[2]*PI/180)      SHP:287-292 */
+  /* libm-evaluated member constants (the reference evaluates them at construction) */
+  double hs_cx, hs_cy;    /* sdHorseshoe c = (cos 20.5, sin 20.5)        SHP:855 */
+  double pie_cx, pie_cy;  /* sdPie c = (cos 43, sin 43)                  SHP:1237 */
+  double pie2_cx, pie2_cy;/* sdPie2 c = (cos 1, sin 1)                   SHP:1278 */
+  double arc_scx, arc_scy;/* sdArc sc = (sin 20, cos 20)                 SHP:1320 */
+  int nverts;             /* Polygon only                                SHP:1428-1445 */
+  double vx[ORC_MAX_POLY_VERTS], vy[ORC_MAX_POLY_VERTS];
+} orc_shape;
+
+typedef struct orc_traj {
+  int N;
+  double *T;              /* N durations */
+  double *c;              /* per piece: c[(i*6 + k)*3 + d] = coefficient of s^k, dim d */
+  double traj_duration;   /* SWM:376-385 (only updated when total < 300 s) */
+} orc_traj;
+
+/* Work counters (per call of orc_penalty / orc_query; summed over threads). */
+typedef struct orc_counters {
+  long long sdf_evals;        /* SDF-at-time evaluations (SWM:741-750) */
+  long long shape_evals;      /* raw shape SDF evaluations incl. FD gradient */
+  long long solves;           /* getSDFofSweptVolume<false,true> calls */
+  long long interior_points;  /* points entering the GSIP loop */
+  long long gd_trials;        /* gradientDescent inner-loop trials */
+} orc_counters;
+
+typedef struct orc_ctx orc_ctx;
+
+/* ---- shape ---------------------------------------------------------------- */
+int  orc_shape_id_from_name(const char *name);            /* -1 -> not registered */
+const char *orc_shape_name(int id);
+void orc_shape_init(orc_shape *s, int id, const double poly_params[3],
+                    const double *poly_xy, int nverts);
+double orc_shape_sdf(const orc_shape *s, double x, double y);           /* getonlySDF(pos_rel) */
+void orc_shape_grad(const orc_shape *s, double x, double y, double g[2]);/* getonlyGrad1 */
+
+/* ---- context ---------------------------------------------------------------- */
+orc_ctx *orc_create(int shape_id, const double poly_params[3],
+                    const double *poly_xy, int nverts,
+                    double safety_hor, double weight_p, double rho,
+                    const double head_state[9], const double tail_state[9]);
+void orc_destroy(orc_ctx *ctx);
+/* MINCO coefficient matrix (6N x 3, COLUMN-major like Eigen::MatrixX3d) + durations. */
+void orc_set_traj(orc_ctx *ctx, int N, const double *coeffs_colmajor, const double *T);
+double orc_traj_duration(const orc_ctx *ctx);
+void orc_traj_pos(const orc_ctx *ctx, double t, double out[3]);   /* TRJ:518-522 */
+void orc_traj_vel(const orc_ctx *ctx, double t, double out[3]);   /* TRJ:524-528 */
+double orc_sdf_at_time(orc_ctx *ctx, double px, double py, double t); /* SWM:741-750 */
+
+/* getSDFofSweptVolume<false,true> (SWM:844-866): returns sdf*, writes t* and grad. */
+double orc_sdf_swept(orc_ctx *ctx, double px, double py, double *t_star, double grad[3]);
+/* getTrueSDFofSweptVolume<true> (SWM:916-1018). */
+double orc_true_sdf(orc_ctx *ctx, double px, double py, double *t_star, double grad[3]);
+
+/* Per-point query of a2 for P points (xyz AoS, z ignored): outputs may be NULL. */
+void orc_query(orc_ctx *ctx, const double *xyz, size_t P, int nthreads,
+               double *sdf, double *tstar, double *grad_xy /* 2 per point */);
+
+/*
+ * addSaftyPenaOnSweptVolumeParallelTrueSDF (BEO:774-869): accumulates (+=) into
+ * cost / gradT[N] / gradC[6N x 3 col-major].  sum_mode 0 = double accumulation in
+ * index order (serial twin BEO:624-772), 1 = long-double accumulation in index order.
+ * nthreads > 1 uses the reference's OpenMP structure (schedule(dynamic)); contributions
+ * are still reduced in index order so results do not depend on nthreads.
+ * Optional per-point outputs (may be NULL): sdf[P], tstar[P], pcost[P] (w*L).
+ */
+void orc_penalty(orc_ctx *ctx, const double *xyz, size_t P, int nthreads, int sum_mode,
+                 double *cost, double *gradT, double *gradC,
+                 double *sdf, double *tstar, double *pcost);
+
+void orc_get_counters(const orc_ctx *ctx, orc_counters *out);
+
+/* ---- MINCO S3NU + full callback (a14) --------------------------------------- */
+/* x = [tau_0..tau_{N-1}, q_0 (x,y,yaw), ..., q_{N-2}], n = N + 3(N-1). Returns cost,
+ * overwrites g[0..n).  BEO:344-408.  costs3 (optional) = {cost_pos, cost_other, cost_total}. */
+double orc_cost_function(orc_ctx *ctx, const double *xyz, size_t P, int nthreads,
+                         const double *x, double *g, int n, double *costs3);
+/* MINCO forward only: (points 3x(N-1) col-major, T[N]) -> coeffs 6Nx3 col-major. MNC:433-513 */
+void orc_minco_coeffs(const double head_state[9], const double tail_state[9], int N,
+                      const double *inPs, const double *T, double *coeffs_colmajor);
+void orc_forward_T(const double *tau, double *T, int N);   /* BEO:213-226 */
+void orc_backward_T(const double *T, double *tau, int N);  /* BEO:228-241 */
+int orc_smoothed_l1(double x, double mu, double *f, double *df); /* BEO:316-340 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

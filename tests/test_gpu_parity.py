@@ -1,0 +1,165 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): gradient vector <= 1e-5 relative (L2); cost <= 1e-7 relative here (the
+per-point argmin is iterative, so t* agrees to ~1e-8 and the cost to ~1e-9).  Per-point basin
+flips (|t*_hip - t*_oracle| > 1e-6) are counted and must stay rare.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+NT = os.cpu_count() or 1
+
+
+def _mk(config, P, N=None, dist="corridor", seed=None):
+    import svsdf_amd
+    from svsdf_amd import workload
+    kw = {} if seed is None else {"seed": seed}
+    w = workload.make(config, P=P, N=N, dist=dist, minco=svsdf_amd.minco_coeffs, **kw)
+    ctx = svsdf_amd.SvsdfContext(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"],
+                                 rho=w["rho"], poly_params=w["poly_params"], polygon=w["polygon"],
+                                 head_state=w["head_state"], tail_state=w["tail_state"], device=0)
+    ctx.set_points(w["points"])
+    o = orc.Oracle(w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
+                   poly_params=w["poly_params"], polygon=w["polygon"],
+                   head_state=w["head_state"], tail_state=w["tail_state"])
+    o.set_traj(w["coeffs"], w["T"])
+    return w, ctx, o
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+@pytest.mark.parametrize("config,P", [("C1", 3000), ("C2", 2000)])
+def test_per_point_queries_match_oracle(built, config, P):
+    w, ctx, o = _mk(config, P)
+    sdf, ts, g, idx = ctx.query_points(w["coeffs"], w["T"])
+    assert np.array_equal(idx, np.arange(P))
+    osdf, ots, og = o.query(w["points"], nthreads=NT)
+    flips = np.abs(ts - ots) > 1e-6
+    assert flips.mean() <= 2e-3, flips.sum()
+    ok = ~flips
+    ext = ok & (osdf > 0)
+    np.testing.assert_allclose(sdf[ext], osdf[ext], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(g[ext], og[ext], rtol=0, atol=2e-6)   # FD gradient, dx = 1e-6
+    itr = ok & (osdf <= 0)
+    assert itr.sum() > 0.1 * P
+    np.testing.assert_allclose(sdf[itr], osdf[itr], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(g[itr], og[itr], rtol=0, atol=1e-6)
+    st = ctx.stats()
+    cnt = o.counters()
+    assert st["interior_points"] == cnt["interior_points"]
+    assert st["solves"] == cnt["solves"]
+
+
+@pytest.mark.parametrize("config,P,N", [("C1", 4000, None), ("C2", 3000, None), ("C3", 2000, None),
+                                        ("C4", 2000, None), ("C5", 1000, 8)])
+def test_penalty_matches_oracle(built, config, P, N):
+    w, ctx, o = _mk(config, P, N=N)
+    Np = len(w["T"])
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
+    assert ocost > 0
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost), (cost, ocost)
+    assert _rel(gC, ogC) <= 1e-5, _rel(gC, ogC)
+    assert _rel(gT, ogT) <= 1e-5, _rel(gT, ogT)
+    # accumulate-into semantics (BEO:774-779: += on cost / gradT / gradC)
+    c0, t0, C0 = 3.5, np.arange(Np, dtype=float), np.ones((6 * Np, 3))
+    cost2, gT2, gC2 = ctx.eval_penalty(w["coeffs"], w["T"], c0, t0, C0)
+    assert abs((cost2 - c0) - cost) <= 1e-9 * abs(cost)
+    np.testing.assert_allclose(gT2 - t0, gT, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gC2 - C0, gC, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("config,P", [("C1", 3000), ("C2", 1500), ("C3", 1000)])
+def test_full_callback_matches_oracle(built, config, P):
+    import svsdf_amd
+    from svsdf_amd import workload
+    w, ctx, o = _mk(config, P)
+    x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+    # perturb so that tau/T are not all equal
+    rng = np.random.default_rng(5)
+    x = x + 0.05 * rng.standard_normal(len(x))
+    f, g = ctx.lmbm_evaluate(x)
+    fo, go, c3 = o.cost_function(w["points"], x, nthreads=NT)
+    assert abs(f - fo) <= 1e-7 * abs(fo), (f, fo)
+    assert _rel(g, go) <= 1e-5, _rel(g, go)
+    np.testing.assert_allclose(ctx.last_costs(), c3, rtol=1e-7)
+
+
+@pytest.mark.parametrize("shape", ["sdUnevenCapsule", "sdCutDisk", "sdTrapezoid", "sdRhombus", "sdTunnel",
+                                   "sdOrientedVesica", "sdRoundedCross", "sdRoundedX", "bigX", "sdMoon",
+                                   "sdPie", "sdPie2", "sdArc", "Polygon"])
+def test_every_shape_matches_oracle(built, shape):
+    """All 16 registered shapes + the fallback Polygon rectangle (SWM:363-369)."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    pp = (0.0, -3.0, 0.0) if shape == "sdCutDisk" else ((0.3, -0.2, 25.0) if shape == "sdPie" else (0.0, 0.0, 0.0))
+    base = workload.make("C1", P=600, minco=svsdf_amd.minco_coeffs)
+    kw = dict(safety_hor=0.7, weight_p=60.0, rho=3.8, poly_params=pp,
+              head_state=base["head_state"], tail_state=base["tail_state"])
+    ctx = svsdf_amd.SvsdfContext(shape=shape, device=0, **kw)
+    ctx.set_points(base["points"])
+    o = orc.Oracle(shape, **kw)
+    o.set_traj(base["coeffs"], base["T"])
+    cost, gT, gC = ctx.eval_penalty(base["coeffs"], base["T"])
+    ocost, ogT, ogC = o.penalty(base["points"], nthreads=NT, sum_mode=1)
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost), (cost, ocost)
+    assert _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5
+
+
+def test_edge_cases(built):
+    import svsdf_amd
+    from svsdf_amd import workload
+    w, ctx, o = _mk("C1", 64)
+    # single point, far away: contributes exactly zero
+    ctx.set_points(np.array([[500.0, 500.0, 3.0]]))
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    assert cost == 0.0 and not gT.any() and not gC.any()
+    # z is ignored (BEO:790-791)
+    p = w["points"][:32].copy()
+    ctx.set_points(p)
+    a = ctx.eval_penalty(w["coeffs"], w["T"])
+    p[:, 2] = 7.0
+    ctx.set_points(p)
+    b = ctx.eval_penalty(w["coeffs"], w["T"])
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])
+    # evaluate before set_points / bad n
+    c2 = svsdf_amd.SvsdfContext(shape="star", device=0)
+    with pytest.raises(svsdf_amd.SvsdfError):
+        c2.eval_penalty(w["coeffs"], w["T"])
+    with pytest.raises(svsdf_amd.SvsdfError):
+        ctx.lmbm_evaluate(np.zeros(6))
+    # N = 1 (no interior waypoints) works
+    hs, ts = w["head_state"], w["tail_state"]
+    c1 = svsdf_amd.minco_coeffs(hs, ts, np.zeros((0, 3)), np.array([30.0]))
+    ctx.set_points(w["points"])
+    cost1, _, _ = ctx.eval_penalty(c1, np.array([30.0]))
+    o.set_traj(c1, np.array([30.0]))
+    oc1, _, _ = o.penalty(w["points"], nthreads=NT)
+    assert abs(cost1 - oc1) <= 1e-7 * max(abs(oc1), 1.0)
+
+
+def test_sharded_contexts_sum_to_whole(built):
+    """world_size-2 sharding in one process: the two shard partials add up to the full result."""
+    import svsdf_amd
+    w, ctx, o = _mk("C1", 2000)
+    full = ctx.eval_penalty(w["coeffs"], w["T"])
+    acc_c, acc_T, acc_C = 0.0, np.zeros_like(full[1]), np.zeros_like(full[2])
+    seen = []
+    for r in range(2):
+        c = svsdf_amd.SvsdfContext(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"],
+                                   rho=w["rho"], head_state=w["head_state"], tail_state=w["tail_state"],
+                                   device=0, rank=r, world_size=2)
+        c.set_points(w["points"])
+        seen.append(c.shard_indices())
+        acc_c, acc_T, acc_C = c.eval_penalty(w["coeffs"], w["T"], acc_c, acc_T, acc_C)
+    assert sorted(np.concatenate(seen).tolist()) == list(range(2000))
+    assert abs(acc_c - full[0]) <= 1e-10 * abs(full[0])
+    np.testing.assert_allclose(acc_C, full[2], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(acc_T, full[1], rtol=1e-9, atol=1e-9)
