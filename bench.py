@@ -99,6 +99,7 @@ def main():
     opt.setConditions(w["head_state"], w["tail_state"], N)
     opt.setPoints(w["points"])          # uploaded once; each rank keeps its stripe in HBM
     ctx = opt._context()
+    ctx.set_profiling(True)   # HIP events around every k_refine launch (the dominant kernel)
 
     def step():
         return opt.addSaftyPenaOnSweptVolumeParallelTrueSDF(w["T"], w["coeffs"], 0.0, np.zeros(N), np.zeros((6 * N, 3)))
@@ -138,7 +139,7 @@ def main():
         return
     ms_per_step = 1e3 * elapsed / a.steps
     value = P_total * a.steps / elapsed
-    # dominant kernel = k_solve (argmin over t); rank-0 HIP-event time on the library's stream
+    # dominant kernel = k_refine; rank-0 HIP-event time on the library's own streams
     solve_ms_step = solve_ms / a.steps
     shard = ctx.num_points()
     ach_gbs = BYTES_PER_POINT * shard / (solve_ms_step * 1e-3) / 1e9
@@ -154,7 +155,7 @@ def main():
                    "interior_fraction": interior_all / a.steps / P_total,
                    "argmin_solves_per_point": solves_all / a.steps / P_total,
                    "parallelism": f"points striped over {world} GPU(s), 1 all-reduce of {19 * N + 1} f64"},
-        "roofline": {"bound": "hbm", "kernel": "k_solve (argmin over t; all launches of one evaluation)",
+        "roofline": {"bound": "hbm", "kernel": "k_refine (argmin over t: scan layers 2-4 + descent; all launches of one evaluation)",
                      "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                      "traffic": None,
                      "kernel_ms_per_step": solve_ms_step, "launches_per_step": launches / a.steps,

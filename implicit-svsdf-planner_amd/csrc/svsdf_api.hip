@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -29,15 +30,20 @@ thread_local std::string g_last_error;
 struct svsdf_ctx {
   svsdf_config cfg{};
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;               // main stream: upload, prep, assemble, readback
+  hipStream_t bstream[kMaxBatches] = {};      // one stream per point batch
+  hipEvent_t ev_prep = nullptr, ev_done[kMaxBatches] = {};
   ShapeParams sp{};
   double *d_poly = nullptr;
   std::string err;
 
-  // points: this rank's shard, Morton-sorted
+  // points: this rank's shard, Morton-sorted, split into nbatch contiguous batches
   size_t P = 0;
   std::vector<long long> shard_idx;  // original index of shard element j
   double *d_px = nullptr, *d_py = nullptr;
+  int nbatch = 1;
+  int bstart[kMaxBatches] = {}, bcount[kMaxBatches] = {};
+  BatchCtl *d_ctl = nullptr;
 
   // trajectory
   TrajDev *d_traj = nullptr;
@@ -45,26 +51,33 @@ struct svsdf_ctx {
   double *h_in = nullptr;  // pinned mirror
   size_t in_cap = 0;       // doubles
   Pose *d_pose = nullptr;
+  Chunk *d_chunks = nullptr;
   size_t pose_cap = 0;
+  double r_bound = 0.0;    // shape bound radius for the layer-1 chunk pruning
   double traj_duration = 0.0;
   bool have_duration = false;
   int N = 0, K = 0;
 
-  // per-point buffers
-  double *d_sdf = nullptr, *d_t = nullptr;
+  // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
+  int G = 4, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
+
+  // per-point / per-sub-query buffers
+  double *d_seed_t = nullptr, *d_seed_min = nullptr, *d_sdf = nullptr, *d_t = nullptr;
   double *d_res_sdf = nullptr, *d_res_t = nullptr, *d_res_gx = nullptr, *d_res_gy = nullptr;
+  double *d_sq_seed_t = nullptr, *d_sq_seed_min = nullptr;
   GsipState gs{};
-  int *d_counters = nullptr;              // [0] n_interior, [1] n_active, [2] nonfinite
-  unsigned long long *d_stats = nullptr;  // [0] solves, [1] evals, [2] layer-1 evals
   double *d_block_partials = nullptr;
   size_t block_partials_cap = 0;  // doubles
-  double *d_partial = nullptr;    // 19 * kMaxPieces + 1
-  double *h_partial = nullptr;    // pinned
+  double *d_sums = nullptr;       // 19 * kMaxPieces + 1
+  double *d_out = nullptr;        // [partial (19 * kMaxPieces + 1) | 8 x u64 stats]
+  double *h_out = nullptr;        // pinned mirror
+  int *d_nonfinite = nullptr;
 
   // profiling
-  bool profile = true;
+  bool profile = false;  // per-launch HIP events (env SVSDF_PROFILE=1 or svsdf_set_profiling)
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  std::vector<std::pair<size_t, size_t>> refine_events;  // (start, stop) indices into ev_pool
   svsdf_stats stats{};
 
   // full-callback state (TrajOptimizer members BEO:44-60)
@@ -75,6 +88,9 @@ struct svsdf_ctx {
 };
 
 namespace {
+
+constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
+constexpr size_t kOutDoubles = kOutPartial + 8;
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -111,16 +127,23 @@ inline uint32_t part1by1(uint32_t x) {
   return x;
 }
 
-hipEvent_t next_event(svsdf_ctx *ctx) {
+size_t next_event(svsdf_ctx *ctx) {
   if (ctx->ev_used == ctx->ev_pool.size()) {
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     ctx->ev_pool.push_back(e);
   }
-  return ctx->ev_pool[ctx->ev_used++];
+  return ctx->ev_used++;
 }
 
 // ---- kernel dispatch over the shape id ---------------------------------------------------------
+#ifdef SVSDF_FAST_BUILD  // development builds: star / sdHorseshoe / sdHeart / Polygon only
+#define SVSDF_FOR_SHAPE(id, CALL)                       \
+  switch (id) {                                         \
+    case 4: CALL(4); break;   case 6: CALL(6); break;   \
+    case 7: CALL(7); break;   default: CALL(16); break; \
+  }
+#else
 #define SVSDF_FOR_SHAPE(id, CALL)                       \
   switch (id) {                                         \
     case 0: CALL(0); break;   case 1: CALL(1); break;   \
@@ -133,31 +156,64 @@ hipEvent_t next_event(svsdf_ctx *ctx) {
     case 14: CALL(14); break; case 15: CALL(15); break; \
     default: CALL(16); break;                           \
   }
+#endif
 
-void launch_solve(svsdf_ctx *ctx, const double *qx, const double *qy, int n_inner, int n_outer,
-                  size_t stride, double *out_sdf, double *out_t) {
-  const long long total = (long long)n_inner * n_outer;
-  if (total <= 0) return;
-  const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
+// One argmin solve launch pair (k_seed + k_refine) over a query set on stream `st`.
+// max_queries bounds the (possibly device-side) query count and sizes the persistent grids.
+template <int S, int G>
+void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries,
+                     double *seed_t, double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
+                     int work_base) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
-  if (ctx->profile) (void)hipEventRecord(next_event(ctx), ctx->stream);
-#define CALL(S)                                                                                  \
-  hipLaunchKernelGGL((k_solve<S>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_traj, d_tk,  \
-                     ctx->d_pose, ctx->sp, qx, qy, n_inner, n_outer, stride, out_sdf, out_t,     \
-                     ctx->d_stats)
-  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
-  if (ctx->profile) (void)hipEventRecord(next_event(ctx), ctx->stream);
+  const long long lanes = std::max<long long>(max_queries * G, 64);
+  // seed: 256-thread persistent blocks, pose + chunk tables in LDS
+  const size_t seed_lds = (4 * (size_t)ctx->K + 4 * (size_t)((ctx->K + kChunk - 1) / kChunk)) * sizeof(double);
+  const unsigned seed_grid = (unsigned)std::min<long long>((lanes + kBlock - 1) / kBlock, 1024);
+  hipLaunchKernelGGL((k_seed<S, G>), dim3(seed_grid), dim3(kBlock), seed_lds, st, ctx->d_traj, d_tk, ctx->d_pose,
+                     ctx->d_chunks, ctx->sp, qs, seed_t, seed_min, ctx->prune, ctl, work_base);
+  // refine: small persistent blocks (fine-grained dynamic fetch), trajectory in LDS
+  const int blk = ctx->block;
+  const size_t ref_lds = (size_t)traj_lds_doubles(ctx->N) * sizeof(double);
+  const unsigned ref_grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
+  size_t e0 = 0, e1 = 0;
+  if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
+  hipLaunchKernelGGL((k_refine<S, G>), dim3(ref_grid), dim3(blk), ref_lds, st, ctx->d_traj, ctx->sp, qs, seed_t,
+                     seed_min, out_sdf, out_t, ctl, work_base + 1);
+  if (ctx->profile) {
+    e1 = next_event(ctx);
+    (void)hipEventRecord(ctx->ev_pool[e1], st);
+    ctx->refine_events.emplace_back(e0, e1);
+  }
   ctx->stats.solve_launches++;
 }
 
-void launch_classify(svsdf_ctx *ctx) {
-  const unsigned grid = (unsigned)((ctx->P + kBlock - 1) / kBlock);
-#define CALL(S)                                                                                   \
-  hipLaunchKernelGGL((k_classify<S>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_traj,      \
-                     ctx->sp, ctx->d_px, ctx->d_py, (int)ctx->P, ctx->d_sdf, ctx->d_t,            \
-                     ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->P, \
-                     ctx->d_counters)
+template <int S>
+void launch_solve_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long max_queries,
+                    double *seed_t, double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
+                    int work_base) {
+  switch (G) {
+    case 1: launch_solve_sg<S, 1>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
+    case 2: launch_solve_sg<S, 2>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
+    case 8: launch_solve_sg<S, 8>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
+    default: launch_solve_sg<S, 4>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
+  }
+}
+
+void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long max_queries,
+                  double *seed_t, double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
+                  int work_base) {
+#define CALL(S) launch_solve_s<S>(ctx, G, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base)
+  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+}
+
+void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
+  const unsigned grid = (unsigned)std::min<long long>(((long long)ctx->bcount[b] + kBlock - 1) / kBlock, 2048);
+  const size_t lds = (size_t)traj_lds_doubles(ctx->N) * sizeof(double);
+#define CALL(S)                                                                                      \
+  hipLaunchKernelGGL((k_classify<S>), dim3(grid), dim3(kBlock), lds, st, ctx->d_traj, ctx->sp,       \
+                     ctx->d_px, ctx->d_py, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,       \
+                     ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->P, ctx->d_ctl + b)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
 }
@@ -176,6 +232,7 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   const double dur = ctx->traj_duration;
   size_t K = 0;
   for (double t = 0.0; t <= dur; t += 0.15) ++K;
+  if (K > 16000) return fail(ctx, SVSDF_ERR_INVALID, "trajectory duration too long for the scan table");
   const size_t need = 19 * (size_t)N + K;
   if (need > ctx->in_cap) {
     const size_t cap = need + 4096;
@@ -188,6 +245,8 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   }
   if (K > ctx->pose_cap) {
     int rc = dev_alloc(ctx, &ctx->d_pose, K + 1024);
+    if (rc) return rc;
+    rc = dev_alloc(ctx, &ctx->d_chunks, (K + 1024) / kChunk + 2);
     if (rc) return rc;
     ctx->pose_cap = K + 1024;
   }
@@ -203,94 +262,116 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   ctx->N = N;
   ctx->K = (int)K;
   HIPCHK(hipMemcpyAsync(ctx->d_in, ctx->h_in, need * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_in, ctx->d_in + 18 * N, N,
-                     dur, (int)K, ctx->d_in + 19 * N, ctx->d_traj, ctx->d_pose);
+  const size_t lds = (size_t)traj_lds_doubles(N) * sizeof(double);
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), lds, ctx->stream, ctx->d_in, N, dur, (int)K, ctx->d_traj,
+                     ctx->d_pose, ctx->d_chunks, ctx->r_bound, ctx->d_ctl, ctx->nbatch);
   return SVSDF_OK;
 }
 
-// Device pipeline up to the per-point results of getTrueSDFofSweptVolume (res_* arrays).
-int run_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+// samples per GSIP round: 2, 6, 18, 21, 21, ... (+1 for accumulated-angle rounding), SWM:60-71,105-110
+const int kRoundSlots[kMaxRounds] = {3, 7, 19, 22, 22, 22, 22, 22, 22};
+
+// Enqueue the device pipeline up to the per-point results of getTrueSDFofSweptVolume (res_*).
+// No host synchronisation: batches run on their own streams, joined back onto ctx->stream.
+int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   if (ctx->P == 0) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->ev_used = 0;
+  ctx->refine_events.clear();
   ctx->stats = svsdf_stats{};
   ctx->stats.points = ctx->P;
-  hipEvent_t e_begin = next_event(ctx);
-  (void)hipEventRecord(e_begin, ctx->stream);
+  const size_t e_begin = next_event(ctx);
+  (void)hipEventRecord(ctx->ev_pool[e_begin], ctx->stream);
   int rc = upload_traj(ctx, N, coeffs, T);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(int), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
-  // main queries
-  launch_solve(ctx, ctx->d_px, ctx->d_py, (int)ctx->P, 1, ctx->P, ctx->d_sdf, ctx->d_t);
-  launch_classify(ctx);
-  int n_int = 0;
-  HIPCHK(hipMemcpyAsync(&n_int, ctx->d_counters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->stats.interior_points = (unsigned long long)n_int;
-  // GSIP rounds (SWM:965-1009): at most 9
-  int n_active = n_int;
-  for (int round = 0; round < 9 && n_active > 0; ++round) {
-    launch_solve(ctx, ctx->gs.sqx, ctx->gs.sqy, n_int, kMaxSlots, ctx->P, ctx->gs.sq_sdf, ctx->gs.sq_t);
-    HIPCHK(hipMemsetAsync(ctx->d_counters + 1, 0, sizeof(int), ctx->stream));
-    const unsigned grid = (unsigned)((n_int + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_gsip, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_px, ctx->d_py, ctx->gs,
-                       ctx->P, n_int, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                       ctx->d_counters + 1);
-    HIPCHK(hipMemcpyAsync(&n_active, ctx->d_counters + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
+  // enqueue round-robin over the batches so that every stream has work early
+  for (int b = 0; b < ctx->nbatch; ++b) {
+    hipStream_t st = ctx->bstream[b];
+    BatchCtl *ctl = ctx->d_ctl + b;
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_prep, 0));
+    QuerySet qm{};
+    qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
+    qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
+    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctl, 0);
+    launch_classify(ctx, st, b);
+  }
+  for (int r = 0; r < kMaxRounds; ++r) {
+    for (int b = 0; b < ctx->nbatch; ++b) {
+      hipStream_t st = ctx->bstream[b];
+      BatchCtl *ctl = ctx->d_ctl + b;
+      QuerySet qsub{};
+      qsub.qx = ctx->gs.sqx; qsub.qy = ctx->gs.sqy; qsub.stride = ctx->P;
+      qsub.count_ptr = &ctl->n_active[r]; qsub.count_fixed = 0;
+      qsub.list = ctx->gs.list[r & 1] + ctx->bstart[b]; qsub.base = ctx->bstart[b]; qsub.n_outer = kRoundSlots[r];
+      const int G = (r >= 4) ? ctx->G_late : ctx->G;
+      launch_solve(ctx, G, st, qsub, (long long)ctx->bcount[b] * kRoundSlots[r], ctx->d_sq_seed_t,
+                   ctx->d_sq_seed_min, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl, 2 * (r + 1));
+      const unsigned grid = (unsigned)std::min<long long>(((long long)ctx->bcount[b] + kBlock - 1) / kBlock, 1024);
+      hipLaunchKernelGGL(k_gsip, dim3(grid), dim3(kBlock), 0, st, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, r,
+                         ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctl);
+    }
+  }
+  for (int b = 0; b < ctx->nbatch; ++b) {
+    HIPCHK(hipEventRecord(ctx->ev_done[b], ctx->bstream[b]));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
   }
   HIPCHK(hipGetLastError());
   return SVSDF_OK;
 }
 
-int finish_stats(svsdf_ctx *ctx, hipEvent_t e_end) {
-  unsigned long long st[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpy(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+// k_finish gathers partial + counters into d_out; one D2H copy brings everything to the host.
+int finish(svsdf_ctx *ctx, bool with_partial) {
+  const int N = ctx->N;
+  if (!with_partial) HIPCHK(hipMemsetAsync(ctx->d_sums, 0, kOutPartial * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
+                     ctx->nbatch, reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
+  const size_t e_end = next_event(ctx);
+  (void)hipEventRecord(ctx->ev_pool[e_end], ctx->stream);
+  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  int nonfinite = 0;
+  HIPCHK(hipMemcpyAsync(&nonfinite, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out + kOutPartial);
   ctx->stats.solves = st[0];
   ctx->stats.sdf_evals = st[1];
   ctx->stats.scan_evals = st[2];
-  if (ctx->profile && ctx->ev_used >= 2) {
+  ctx->stats.interior_points = st[3];
+  if (ctx->profile) {
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], e_end);
+    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[e_end]);
     ctx->stats.device_ms = ms;
     double sum = 0.0;
-    // events: [0] begin, then (start, stop) pairs per solve launch, last = end
-    for (size_t i = 1; i + 1 < ctx->ev_used - 1; i += 2) {
+    for (const auto &pr : ctx->refine_events) {
       float m = 0.f;
-      if (hipEventElapsedTime(&m, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess) sum += m;
+      if (hipEventElapsedTime(&m, ctx->ev_pool[pr.first], ctx->ev_pool[pr.second]) == hipSuccess) sum += m;
     }
     ctx->stats.solve_ms = sum;
   }
+  if (nonfinite || st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
 }
 
-// Whole device pipeline; leaves [cost, gradC, gradT] (19N+1 doubles) in ctx->d_partial.
+// Whole device pipeline; leaves [cost, gradC, gradT] (19N+1 doubles) in d_out / h_out.
 int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
-  int rc = run_queries(ctx, N, coeffs, T);
+  int rc = enqueue_queries(ctx, N, coeffs, T);
   if (rc) return rc;
-  const unsigned grid = (unsigned)((ctx->P + kBlock - 1) / kBlock);
+  const unsigned grid = (unsigned)std::min<size_t>((ctx->P + kBlock - 1) / kBlock, 512);
   const size_t plen = 19 * (size_t)N + 1;
   if ((size_t)grid * plen > ctx->block_partials_cap) {
     rc = dev_alloc(ctx, &ctx->d_block_partials, (size_t)grid * plen);
     if (rc) return rc;
     ctx->block_partials_cap = (size_t)grid * plen;
   }
-  hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_traj, ctx->d_px,
-                     ctx->d_py, (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                     ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_counters + 2);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_block_partials, (int)grid, N,
-                     ctx->d_partial);
-  hipEvent_t e_end = next_event(ctx);
-  (void)hipEventRecord(e_end, ctx->stream);
-  int nonfinite = 0;
-  HIPCHK(hipMemcpyAsync(&nonfinite, ctx->d_counters + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipGetLastError());
-  rc = finish_stats(ctx, e_end);
-  if (rc) return rc;
-  if (nonfinite) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
-  return SVSDF_OK;
+  const size_t lds = ((size_t)traj_lds_doubles(N) + plen) * sizeof(double);
+  hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
+                     (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
+                     ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite);
+  hipLaunchKernelGGL(k_final, dim3((unsigned)plen), dim3(64), 0, ctx->stream, ctx->d_block_partials, (int)grid,
+                     ctx->d_sums);
+  return finish(ctx, true);
 }
 
 void accumulate(int N, const double *partial, double *cost, double *gradT, double *gradC) {
@@ -303,6 +384,8 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   int rc = 0;
   if ((rc = dev_alloc(ctx, &ctx->d_px, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_py, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_seed_t, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_seed_min, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_sdf, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_t, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_res_sdf, P))) return rc;
@@ -315,18 +398,22 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.theta_res, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.iter, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.nsamp, P))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->gs.done, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.list[0], P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.list[1], P))) return rc;
   const size_t S = P * kMaxSlots;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqx, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqy, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqth, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_sdf, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_t, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_sq_seed_t, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_sq_seed_min, S))) return rc;
   return SVSDF_OK;
 }
 
 int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
   // Morton order so that the 64 lanes of a wave hold spatially adjacent points (similar t*,
   // similar iteration counts, same interior/exterior class); the sum is order-independent.
   std::vector<long long> order(P);
@@ -335,8 +422,10 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
     double xmin = std::numeric_limits<double>::infinity(), xmax = -xmin, ymin = xmin, ymax = -xmin;
     for (size_t i = 0; i < P; ++i) {
       const double x = xyz[3 * i], y = xyz[3 * i + 1];
-      if (x < xmin) xmin = x; if (x > xmax) xmax = x;
-      if (y < ymin) ymin = y; if (y > ymax) ymax = y;
+      if (x < xmin) xmin = x;
+      if (x > xmax) xmax = x;
+      if (y < ymin) ymin = y;
+      if (y > ymax) ymax = y;
     }
     const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
     std::vector<uint64_t> key(P);
@@ -352,6 +441,7 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   ctx->shard_idx.clear();
   for (size_t k = (size_t)rk; k < P; k += (size_t)ws) ctx->shard_idx.push_back(order[k]);
   const size_t Ps = ctx->shard_idx.size();
+  if (Ps > 0x3fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard");
   ctx->P = Ps;
   int rc = alloc_point_buffers(ctx, Ps);
   if (rc) return rc;
@@ -363,6 +453,20 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   }
   HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
+  // batches: contiguous ranges of the sorted shard, pipelined on separate streams
+  int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;
+  nb = std::max(1, std::min(nb, kMaxBatches));
+  ctx->nbatch = nb;
+  std::vector<BatchCtl> hc(kMaxBatches);
+  std::memset(hc.data(), 0, sizeof(BatchCtl) * kMaxBatches);
+  for (int b = 0; b < nb; ++b) {
+    const size_t s = Ps * (size_t)b / nb, e = Ps * (size_t)(b + 1) / nb;
+    ctx->bstart[b] = (int)s;
+    ctx->bcount[b] = (int)(e - s);
+    hc[b].start = (int)s;
+    hc[b].count = (int)(e - s);
+  }
+  HIPCHK(hipMemcpy(ctx->d_ctl, hc.data(), sizeof(BatchCtl) * kMaxBatches, hipMemcpyHostToDevice));
   return SVSDF_OK;
 }
 
@@ -455,29 +559,64 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     sp.verts = ctx->d_poly;
     ctx->cfg.polygon_nverts = sp.nverts;
   }
+  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) { ctx->G = g; ctx->G_late = std::max(g, 8); } }
+  if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) ctx->G_late = g; }
+  if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
+  if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
+  if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
+  if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
+  if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
+  for (int b = 0; b < kMaxBatches; ++b) {
+    if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming) != hipSuccess)
+      return bail("stream/event creation failed");
+  }
+  if (hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess) return bail("event creation failed");
   if (hipMalloc((void **)&ctx->d_traj, sizeof(TrajDev)) != hipSuccess ||
-      hipMalloc((void **)&ctx->d_counters, 4 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void **)&ctx->d_stats, 4 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **)&ctx->d_partial, (19 * kMaxPieces + 1) * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void **)&ctx->h_partial, (19 * kMaxPieces + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess)
+      hipMalloc((void **)&ctx->d_ctl, kMaxBatches * sizeof(BatchCtl)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_nonfinite, sizeof(int)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_sums, kOutPartial * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_out, kOutDoubles * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_out, kOutDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
     return bail("device allocation failed");
+  if (hipMemset(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl)) != hipSuccess) return bail("hipMemset failed");
+  {  // shape bound radius R: sdf_shape(q) >= |q| - R, sampled on a polar grid + safety margin
+    if (hipMemset(ctx->d_out, 0, sizeof(double)) != hipSuccess) return bail("hipMemset failed");
+    const int nrad = 512, nang = 4096;
+    const unsigned grid = (unsigned)((nrad * nang + kBlock - 1) / kBlock);
+#define CALL(S) hipLaunchKernelGGL((k_rbound<S>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sp, 60.0, nrad, nang, ctx->d_out)
+    SVSDF_FOR_SHAPE(cfg->shape_id, CALL)
+#undef CALL
+    double rb = 0.0;
+    if (hipMemcpyAsync(&rb, ctx->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+      return bail("shape bound kernel failed");
+    ctx->r_bound = rb + 0.05;
+    ctx->sp.r_bound = ctx->r_bound;
+  }
   return ctx;
 }
 
 void svsdf_destroy(svsdf_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void *bufs[] = {ctx->d_poly, ctx->d_px, ctx->d_py, ctx->d_traj, ctx->d_in, ctx->d_pose, ctx->d_sdf,
-                  ctx->d_t, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs.pt,
-                  ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp,
-                  ctx->gs.done, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth, ctx->gs.sq_sdf, ctx->gs.sq_t,
-                  ctx->d_counters, ctx->d_stats, ctx->d_block_partials, ctx->d_partial};
+  (void)hipDeviceSynchronize();
+  void *bufs[] = {ctx->d_poly, ctx->d_px, ctx->d_py, ctx->d_traj, ctx->d_in, ctx->d_pose, ctx->d_chunks,
+                  ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,
+                  ctx->d_res_gx, ctx->d_res_gy, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctx->gs.pt, ctx->gs.r,
+                  ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.list[0],
+                  ctx->gs.list[1], ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth, ctx->gs.sq_sdf, ctx->gs.sq_t,
+                  ctx->d_ctl, ctx->d_block_partials, ctx->d_sums, ctx->d_out, ctx->d_nonfinite};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_in) (void)hipHostFree(ctx->h_in);
-  if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
+  if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+  for (int b = 0; b < kMaxBatches; ++b) {
+    if (ctx->ev_done[b]) (void)hipEventDestroy(ctx->ev_done[b]);
+    if (ctx->bstream[b]) (void)hipStreamDestroy(ctx->bstream[b]);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -508,7 +647,7 @@ int svsdf_eval_penalty_partial(svsdf_ctx *ctx, int N, const double *coeffs, cons
   if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_eval_penalty_partial: null argument");
   int rc = run_pipeline(ctx, N, coeffs, T);
   if (rc) return rc;
-  if (d_partial) *d_partial = ctx->d_partial;
+  if (d_partial) *d_partial = ctx->d_out;
   if (partial_len) *partial_len = 19 * (size_t)N + 1;
   return SVSDF_OK;
 }
@@ -529,20 +668,15 @@ int svsdf_eval_penalty(svsdf_ctx *ctx, int N, const double *coeffs, const double
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_eval_penalty: null argument");
   int rc = run_pipeline(ctx, N, coeffs, T);
   if (rc) return rc;
-  const size_t plen = 19 * (size_t)N + 1;
-  HIPCHK(hipMemcpy(ctx->h_partial, ctx->d_partial, plen * sizeof(double), hipMemcpyDeviceToHost));
-  return svsdf_accumulate_partial(ctx, N, ctx->h_partial, cost, gradT, gradC);
+  return svsdf_accumulate_partial(ctx, N, ctx->h_out, cost, gradT, gradC);
 }
 
 int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *sdf,
                        double *tstar, double *grad_xy) {
   if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_query_points: null argument");
-  int rc = run_queries(ctx, N, coeffs, T);
+  int rc = enqueue_queries(ctx, N, coeffs, T);
   if (rc) return rc;
-  hipEvent_t e_end = next_event(ctx);
-  (void)hipEventRecord(e_end, ctx->stream);
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  rc = finish_stats(ctx, e_end);
+  rc = finish(ctx, false);
   if (rc) return rc;
   const size_t P = ctx->P;
   if (sdf) HIPCHK(hipMemcpy(sdf, ctx->d_res_sdf, P * sizeof(double), hipMemcpyDeviceToHost));
@@ -553,6 +687,12 @@ int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double
     HIPCHK(hipMemcpy(gy.data(), ctx->d_res_gy, P * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t j = 0; j < P; ++j) { grad_xy[2 * j] = gx[j]; grad_xy[2 * j + 1] = gy[j]; }
   }
+  return SVSDF_OK;
+}
+
+int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
+  if (!ctx) return SVSDF_ERR_INVALID;
+  ctx->profile = enable != 0;
   return SVSDF_OK;
 }
 
@@ -655,10 +795,9 @@ double svsdf_lmbm_evaluate(void *vctx, const double *x, double *g, const int n) 
   const int N = (n + 3) / 4;
   if (run_pipeline(ctx, N, ctx->cm.data(), ctx->T.data())) return inf;
   const size_t plen = 19 * (size_t)N + 1;
-  if (hipMemcpy(ctx->h_partial, ctx->d_partial, plen * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return inf;
   for (size_t e = 0; e < plen; ++e)
-    if (!std::isfinite(ctx->h_partial[e])) return inf;
-  return lmbm_complete(ctx, ctx->h_partial, x, g, n);
+    if (!std::isfinite(ctx->h_out[e])) return inf;
+  return lmbm_complete(ctx, ctx->h_out, x, g, n);
 }
 
 int svsdf_last_costs(const svsdf_ctx *ctx, double costs3[3]) {

@@ -21,7 +21,7 @@ EXPORTS = [
     "svsdf_num_points", "svsdf_eval_penalty", "svsdf_eval_penalty_partial",
     "svsdf_accumulate_partial", "svsdf_lmbm_evaluate", "svsdf_last_costs", "svsdf_lmbm_begin",
     "svsdf_lmbm_finish", "svsdf_minco_coeffs", "svsdf_forward_T", "svsdf_backward_T",
-    "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices",
+    "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices", "svsdf_set_profiling",
 ]
 
 
@@ -44,7 +44,10 @@ class SvsdfError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_PKG, "libsvsdf_hip.so")
+    """In-tree HIP library.  SVSDF_LIB_VARIANT=strict selects the bit-reproducible parity build
+    (libsvsdf_hip_strict.so: no FMA contraction, reference operation order)."""
+    v = os.environ.get("SVSDF_LIB_VARIANT", "")
+    return os.path.join(_PKG, "libsvsdf_hip_%s.so" % v if v else "libsvsdf_hip.so")
 
 
 def lib():
@@ -87,6 +90,7 @@ def lib():
     L.svsdf_query_points.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
     L.svsdf_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.svsdf_shard_indices.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.svsdf_set_profiling.argtypes = [C.c_void_p, C.c_int]
     _LIB = L
     return L
 
@@ -265,6 +269,9 @@ class SvsdfContext:
         idx = self.shard_indices()
         order = np.argsort(idx, kind="stable")
         return sdf[order], ts[order], g[order], idx[order]
+
+    def set_profiling(self, enable=True):
+        self._chk(self.L.svsdf_set_profiling(self.ctx, int(bool(enable))), "svsdf_set_profiling")
 
     def stats(self):
         s = Stats()

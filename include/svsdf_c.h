@@ -159,11 +159,14 @@ typedef struct svsdf_stats {
   unsigned long long solves;          /* argmin solves (main + GSIP sub-queries) */
   unsigned long long sdf_evals;       /* SDF-at-time evaluations executed on the device */
   unsigned long long scan_evals;      /* of which layer-1 table evaluations */
-  double device_ms;                   /* HIP-event time of the whole device pipeline */
-  double solve_ms;                    /* HIP-event time summed over the argmin (solve) kernels */
-  unsigned int solve_launches;
+  double device_ms;                   /* HIP-event time of the whole device pipeline (profiling on) */
+  double solve_ms;                    /* HIP-event time summed over the k_refine launches (profiling on) */
+  unsigned int solve_launches;        /* k_refine launches of the last evaluation */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
+/* Per-launch HIP-event timing of the dominant (argmin refine) kernel on the library's own
+ * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms. */
+int svsdf_set_profiling(svsdf_ctx *ctx, int enable);
 /* Original indices (into the array given to svsdf_set_points) of this rank's shard, in the
  * order svsdf_query_points reports them. */
 int svsdf_shard_indices(const svsdf_ctx *ctx, long long *idx_out);
