@@ -144,6 +144,12 @@ def main():
     shard = ctx.num_points()
     ach_gbs = BYTES_PER_POINT * shard / (solve_ms_step * 1e-3) / 1e9
     ach_tf = (evals / a.steps) * FLOP_PER_EVAL / (solve_ms_step * 1e-3) / 1e12
+    traffic = None
+    try:  # PMC-derived HBM traffic of k_refine per evaluation (collected offline, see profiles/)
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic = tr.get(f"{a.config}:{a.dist}:{per_gpu}")
+    except Exception:
+        pass
     res = {
         "metric": "SVSDF query-points/sec (cost+grad) per optimizer evaluation",
         "value": value, "unit": "query-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -157,7 +163,8 @@ def main():
                    "parallelism": f"points striped over {world} GPU(s), 1 all-reduce of {19 * N + 1} f64"},
         "roofline": {"bound": "hbm", "kernel": "k_refine (argmin over t: scan layers 2-4 + descent; all launches of one evaluation)",
                      "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                     "traffic": None,
+                     "traffic": traffic,
+                     "traffic_unit": "bytes per evaluation (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                      "kernel_ms_per_step": solve_ms_step, "launches_per_step": launches / a.steps,
                      "device_ms_per_step": dev_ms / a.steps,
                      "note": "24 B/point algorithmic; the solve is FP64-VALU bound (SURVEY.md §8d), see fp64",

@@ -56,6 +56,7 @@ struct svsdf_ctx {
   double r_bound = 0.0;    // shape bound radius for the layer-1 chunk pruning
   double traj_duration = 0.0;
   bool have_duration = false;
+  bool host_only = false;  // SVSDF_FLAG_HOST_ONLY: MINCO / callback host logic only, no device
   int N = 0, K = 0;
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
@@ -274,6 +275,7 @@ const int kRoundSlots[kMaxRounds] = {3, 7, 19, 22, 22, 22, 22, 22, 22};
 // Enqueue the device pipeline up to the per-point results of getTrueSDFofSweptVolume (res_*).
 // No host synchronisation: batches run on their own streams, joined back onto ctx->stream.
 int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
   if (ctx->P == 0) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->ev_used = 0;
@@ -411,14 +413,14 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   return SVSDF_OK;
 }
 
-int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipDeviceSynchronize());
+// Morton order + striping: which original indices rank `rk` of `ws` owns, in device order.
+// Pure host code (also exported as svsdf_shard_plan).
+void shard_plan(const double *xyz, size_t P, int rk, int ws, int flags, std::vector<long long> &out) {
   // Morton order so that the 64 lanes of a wave hold spatially adjacent points (similar t*,
   // similar iteration counts, same interior/exterior class); the sum is order-independent.
   std::vector<long long> order(P);
   std::iota(order.begin(), order.end(), 0ll);
-  if (!(ctx->cfg.flags & SVSDF_FLAG_KEEP_INPUT_ORDER) && P > 1) {
+  if (!(flags & SVSDF_FLAG_KEEP_INPUT_ORDER) && P > 1) {
     double xmin = std::numeric_limits<double>::infinity(), xmax = -xmin, ymin = xmin, ymax = -xmin;
     for (size_t i = 0; i < P; ++i) {
       const double x = xyz[3 * i], y = xyz[3 * i + 1];
@@ -437,9 +439,18 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
     }
     std::stable_sort(order.begin(), order.end(), [&](long long a, long long b) { return key[a] < key[b]; });
   }
-  const int ws = std::max(1, ctx->cfg.world_size), rk = ctx->cfg.rank;
-  ctx->shard_idx.clear();
-  for (size_t k = (size_t)rk; k < P; k += (size_t)ws) ctx->shard_idx.push_back(order[k]);
+  ws = std::max(1, ws);
+  out.clear();
+  // stripe (not block) so that every rank gets a spatially uniform subsample: interior points
+  // cost up to ~150x an exterior one and cluster in space
+  for (size_t k = (size_t)rk; k < P; k += (size_t)ws) out.push_back(order[k]);
+}
+
+int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  shard_plan(xyz, P, ctx->cfg.rank, ctx->cfg.world_size, ctx->cfg.flags, ctx->shard_idx);
   const size_t Ps = ctx->shard_idx.size();
   if (Ps > 0x3fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard");
   ctx->P = Ps;
@@ -508,6 +519,13 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
       cfg->rank < 0 || cfg->rank >= cfg->world_size) {
     g_last_error = "svsdf_create: invalid config";
     return nullptr;
+  }
+  if (cfg->flags & SVSDF_FLAG_HOST_ONLY) {
+    svsdf_ctx *h = new svsdf_ctx();
+    h->cfg = *cfg;
+    h->cfg.polygon_xy = nullptr;
+    h->host_only = true;
+    return h;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -599,6 +617,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
 
 void svsdf_destroy(svsdf_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->host_only) { delete ctx; return; }
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {ctx->d_poly, ctx->d_px, ctx->d_py, ctx->d_traj, ctx->d_in, ctx->d_pose, ctx->d_chunks,
@@ -628,6 +647,7 @@ int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P) {
 
 int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P) {
   if (!ctx || (!d_xyz_aos && P)) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_points_device: null argument");
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
   HIPCHK(hipSetDevice(ctx->device));
   std::vector<double> h(3 * P);
   HIPCHK(hipMemcpy(h.data(), d_xyz_aos, 3 * P * sizeof(double), hipMemcpyDeviceToHost));
@@ -654,7 +674,7 @@ int svsdf_eval_penalty_partial(svsdf_ctx *ctx, int N, const double *coeffs, cons
 
 int svsdf_accumulate_partial(svsdf_ctx *ctx, int N, const double *partial_host, double *cost,
                              double *gradT, double *gradC) {
-  if (!ctx || !partial_host || !cost || !gradT || !gradC || N < 1 || N > kMaxPieces)
+  if (!partial_host || !cost || !gradT || !gradC || N < 1 || N > kMaxPieces)  // ctx may be NULL (pure host)
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_accumulate_partial: invalid argument");
   for (int e = 0; e < 19 * N + 1; ++e)
     if (!std::isfinite(partial_host[e])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite partial");
@@ -763,6 +783,25 @@ static double lmbm_complete(svsdf_ctx *ctx, const double *partial, const double 
   for (int i = 0; i + 1 < N; ++i)
     for (int c = 0; c < 3; ++c) g[N + 3 * i + c] = ctx->gradq[i * 3 + c];
   return cost;
+}
+
+int svsdf_shard_plan(const double *xyz_aos, size_t P, int rank, int world_size, int flags,
+                     long long *idx_out, size_t *count_out) {
+  if ((!xyz_aos && P) || rank < 0 || world_size < 1 || rank >= world_size) return SVSDF_ERR_INVALID;
+  std::vector<long long> idx;
+  shard_plan(xyz_aos, P, rank, world_size, flags, idx);
+  if (count_out) *count_out = idx.size();
+  if (idx_out) std::copy(idx.begin(), idx.end(), idx_out);
+  return SVSDF_OK;
+}
+
+int svsdf_lmbm_prepare(svsdf_ctx *ctx, const double *x, int n, double *coeffs_out, double *T_out) {
+  int rc = lmbm_prepare(ctx, x, n);
+  if (rc) return rc;
+  const int N = (n + 3) / 4;
+  if (coeffs_out) std::copy(ctx->cm.begin(), ctx->cm.end(), coeffs_out);
+  if (T_out) std::copy(ctx->T.begin(), ctx->T.begin() + N, T_out);
+  return SVSDF_OK;
 }
 
 int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial, size_t *partial_len) {

@@ -6,9 +6,11 @@ in csrc/ (hand-written HIP).  There is no CPU fallback: every compute call raise
 library or a GPU is missing.
 """
 from .binding import (SHAPES, SHAPE_ID, SvsdfError, SvsdfContext, lib, lib_path, minco_coeffs,
-                      forward_T, backward_T, shape_id_from_inputdata)
+                      forward_T, backward_T, shape_id_from_inputdata, shard_plan,
+                      FLAG_HOST_ONLY, FLAG_KEEP_INPUT_ORDER)
 from .traj_optimizer import TrajOptimizer
 from . import workload
 
 __all__ = ["SHAPES", "SHAPE_ID", "SvsdfError", "SvsdfContext", "TrajOptimizer", "lib", "lib_path",
-           "minco_coeffs", "forward_T", "backward_T", "shape_id_from_inputdata", "workload"]
+           "minco_coeffs", "forward_T", "backward_T", "shape_id_from_inputdata", "shard_plan",
+           "FLAG_HOST_ONLY", "FLAG_KEEP_INPUT_ORDER", "workload"]

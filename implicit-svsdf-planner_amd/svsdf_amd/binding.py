@@ -22,6 +22,7 @@ EXPORTS = [
     "svsdf_accumulate_partial", "svsdf_lmbm_evaluate", "svsdf_last_costs", "svsdf_lmbm_begin",
     "svsdf_lmbm_finish", "svsdf_minco_coeffs", "svsdf_forward_T", "svsdf_backward_T",
     "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices", "svsdf_set_profiling",
+    "svsdf_shard_plan", "svsdf_lmbm_prepare",
 ]
 
 
@@ -91,6 +92,9 @@ def lib():
     L.svsdf_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.svsdf_shard_indices.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.svsdf_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.svsdf_shard_plan.argtypes = [_dp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong),
+                                   C.POINTER(C.c_size_t)]
+    L.svsdf_lmbm_prepare.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp]
     _LIB = L
     return L
 
@@ -137,6 +141,22 @@ def backward_T(T):
     tau = np.zeros_like(T)
     lib().svsdf_backward_T(_p(T), _p(tau), len(T))
     return tau
+
+
+FLAG_KEEP_INPUT_ORDER = 1
+FLAG_HOST_ONLY = 2
+
+
+def shard_plan(xyz, rank, world_size, flags=0):
+    """Original indices owned by `rank` (pure host; same plan svsdf_set_points uses)."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = C.c_size_t()
+    idx = np.zeros(len(xyz), dtype=np.int64)
+    rc = lib().svsdf_shard_plan(_p(xyz), len(xyz), rank, world_size, flags,
+                                idx.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(n))
+    if rc:
+        raise SvsdfError(f"svsdf_shard_plan failed: {rc}")
+    return idx[:n.value].copy()
 
 
 class SvsdfContext:
@@ -247,6 +267,14 @@ class SvsdfContext:
         ptr, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.svsdf_lmbm_begin(self.ctx, _p(x), len(x), C.byref(ptr), C.byref(n)), "svsdf_lmbm_begin")
         return ptr.value, n.value
+
+    def lmbm_prepare(self, x):
+        """Host half of lmbm_begin: returns (coeffs (6N, 3), T (N,)) the device stage receives."""
+        x = _f64(x)
+        N = (len(x) + 3) // 4
+        cm, T = np.zeros(18 * N), np.zeros(N)
+        self._chk(self.L.svsdf_lmbm_prepare(self.ctx, _p(x), len(x), _p(cm), _p(T)), "svsdf_lmbm_prepare")
+        return cm.reshape(3, 6 * N).T.copy(), T
 
     def lmbm_finish(self, partial, n):
         partial = _f64(partial)

@@ -83,6 +83,9 @@ typedef struct svsdf_config {
 
 #define SVSDF_FLAG_DEFAULT 0
 #define SVSDF_FLAG_KEEP_INPUT_ORDER 1 /* do not Morton-sort the cloud at upload (debug) */
+#define SVSDF_FLAG_HOST_ONLY 2        /* no device: only the host-side entry points work
+                                         (svsdf_lmbm_prepare / svsdf_lmbm_finish, MINCO helpers);
+                                         every device entry point fails with SVSDF_ERR_NO_DEVICE */
 
 typedef struct svsdf_ctx svsdf_ctx;
 
@@ -106,6 +109,10 @@ int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P);
 /* Same, but xyz_aos is a DEVICE pointer on ctx's device (inputs already resident in HBM). */
 int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P);
 size_t svsdf_num_points(const svsdf_ctx *ctx);        /* points owned by this rank's shard */
+/* Pure host: the original indices rank `rank` of `world_size` owns (Morton order, striped), in
+ * the order the device stores them.  idx_out may be NULL to query the count. */
+int svsdf_shard_plan(const double *xyz_aos, size_t P, int rank, int world_size, int flags,
+                     long long *idx_out, size_t *count_out);
 
 /* ---- the inner operator ---------------------------------------------------------------------- */
 /* Replaces TrajOptimizer::addSaftyPenaOnSweptVolumeParallelTrueSDF (BEO:774-869):
@@ -137,6 +144,9 @@ int svsdf_last_costs(const svsdf_ctx *ctx, double costs3[3]);
 /* Full callback split around the collective for the one-process-per-GPU form:
  * begin -> all-reduce the device partial -> finish. */
 int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial, size_t *partial_len);
+/* Host half of svsdf_lmbm_begin only: tau -> T, MINCO forward, energy partials (BEO:351-366);
+ * writes the coefficients ((6N) x 3 col-major) and durations the device stage would receive. */
+int svsdf_lmbm_prepare(svsdf_ctx *ctx, const double *x, int n, double *coeffs_out, double *T_out);
 double svsdf_lmbm_finish(svsdf_ctx *ctx, const double *partial_host, double *g, int n);
 
 /* ---- host-side MINCO helpers (MNC:397-655) ------------------------------------------------------- */

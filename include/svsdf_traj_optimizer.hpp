@@ -1,0 +1,140 @@
+// svsdf_traj_optimizer.hpp -- C++ host-side mirror of the reference's TrajOptimizer for the
+// SVSDF cost path, on top of the C ABI (svsdf_c.h).  Header-only; link with libsvsdf_hip.so.
+//
+// Same member names / callback signatures as the reference so that plan_manager code keeps
+// compiling against it (BEO = src/planner_algorithm/include/planner_algorithm/back_end_optimizer.hpp):
+//   TrajOptimizer::costFunctionLmbmParallel(void*, const double*, double*, const int)   BEO:344-408
+//     == lmbm::lmbm_evaluate_t (src/utils/include/utils/lmbm.h:206-209)
+//   TrajOptimizer::addSaftyPenaOnSweptVolumeParallelTrueSDF(ptr, T, coeffs, cost, gradT, gradC)
+//                                                                                        BEO:774-869
+//   cost_pos / cost_other / cost_total                                                   BEO:396-398
+// With Eigen available the Eigen-typed overloads and the lbfgs::lbfgs_evaluate_t adapter
+// (src/utils/include/utils/lbfgs.hpp:213-216) are compiled in as well.
+#pragma once
+#include <cstddef>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "svsdf_c.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define SVSDF_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace svsdf {
+
+class TrajOptimizerHip {
+ public:
+  // --- Config-derived members (BEO:69-95) ---
+  double rho = 3.8;
+  double weight_p = 60.0;
+  double safety_hor = 0.7;
+  int threads_num = 30;  // kept for source compatibility; the GPU path ignores it
+  std::string inputdata = "shapes/star.obj";
+  double poly_params[3] = {0.0, 0.0, 0.0};
+  std::vector<double> polygon_xy;  // optional outline for the Polygon fallback
+  int device = -1;
+  int rank = 0, world_size = 1;
+
+  // --- optimisation state (BEO:44-60) ---
+  int pieceN = 0, temporalDim = 0, spatialDim = 0;
+  double initState[9] = {0}, finalState[9] = {0};  // 3x3 column-major
+  int parallel_points_num = 0;
+  std::vector<double> parallel_points;  // xyz AoS (Eigen::Vector3d layout)
+  double cost_pos = 0.0, cost_other = 0.0, cost_total = 0.0;
+
+  TrajOptimizerHip() = default;
+  TrajOptimizerHip(const TrajOptimizerHip &) = delete;
+  TrajOptimizerHip &operator=(const TrajOptimizerHip &) = delete;
+  ~TrajOptimizerHip() { svsdf_destroy(ctx_); }
+
+  // plan_manager.cpp:168-175
+  void setPoints(const double *xyz_aos, std::size_t P) {
+    parallel_points.assign(xyz_aos, xyz_aos + 3 * P);
+    parallel_points_num = (int)P;
+    points_dirty_ = true;
+  }
+  // first lines of optimize_traj_lmbm (back_end_optimizer.cpp:13-19); initS/finalS 3x3 col-major
+  void setConditions(const double initS[9], const double finalS[9], int N) {
+    pieceN = N; temporalDim = N; spatialDim = 3 * (N - 1);
+    std::memcpy(initState, initS, sizeof(initState));
+    std::memcpy(finalState, finalS, sizeof(finalState));
+    svsdf_destroy(ctx_);
+    ctx_ = nullptr;
+  }
+
+  // static double costFunctionLmbmParallel(void *ptr, const double *x, double *g, const int n)
+  static double costFunctionLmbmParallel(void *ptr, const double *x_variable, double *g, const int n) {
+    TrajOptimizerHip &obj = *static_cast<TrajOptimizerHip *>(ptr);
+    svsdf_ctx *ctx = obj.context();
+    if (!ctx || n != obj.temporalDim + obj.spatialDim) {
+      if (g) std::memset(g, 0, sizeof(double) * (n > 0 ? n : 0));
+      return std::numeric_limits<double>::infinity();
+    }
+    const double cost = svsdf_lmbm_evaluate(ctx, x_variable, g, n);
+    double c3[3] = {0, 0, 0};
+    svsdf_last_costs(ctx, c3);
+    obj.cost_pos = c3[0]; obj.cost_other = c3[1]; obj.cost_total = c3[2];
+    return cost;
+  }
+
+  // static void addSaftyPenaOnSweptVolumeParallelTrueSDF(ptr, T, coeffs, cost, gradT, gradC)
+  // raw-pointer form: T[N], coeffs/gradC (6N) x 3 column-major; accumulates (+=).
+  static int addSaftyPenaOnSweptVolumeParallelTrueSDF(void *ptr, const double *T, const double *coeffs, int N,
+                                                      double &cost, double *gradT, double *gradC) {
+    TrajOptimizerHip &obj = *static_cast<TrajOptimizerHip *>(ptr);
+    svsdf_ctx *ctx = obj.context();
+    if (!ctx) return SVSDF_ERR_NO_DEVICE;
+    return svsdf_eval_penalty(ctx, N, coeffs, T, &cost, gradT, gradC);
+  }
+
+#ifdef SVSDF_HAVE_EIGEN
+  static void addSaftyPenaOnSweptVolumeParallelTrueSDF(void *ptr, const Eigen::VectorXd &T,
+                                                       const Eigen::MatrixX3d &coeffs, double &cost,
+                                                       Eigen::VectorXd &gradT, Eigen::MatrixX3d &gradC) {
+    const int rc = addSaftyPenaOnSweptVolumeParallelTrueSDF(ptr, T.data(), coeffs.data(), (int)T.size(), cost,
+                                                            gradT.data(), gradC.data());
+    if (rc) throw std::runtime_error("svsdf_eval_penalty failed: " + std::to_string(rc));
+  }
+  // lbfgs::lbfgs_evaluate_t adapter (lbfgs.hpp:213-216): p_cost receives cost_pos
+  static double costFunctionLbfgs(void *ptr, const Eigen::VectorXd &x, Eigen::VectorXd &g, double &p_cost) {
+    const double f = costFunctionLmbmParallel(ptr, x.data(), g.data(), (int)x.size());
+    p_cost = static_cast<TrajOptimizerHip *>(ptr)->cost_pos;
+    return f;
+  }
+#endif
+
+  svsdf_ctx *context() {
+    if (!ctx_) {
+      svsdf_config cfg;
+      svsdf_config_default(&cfg);
+      cfg.shape_id = polygon_xy.empty() ? svsdf_shape_id_from_inputdata(inputdata.c_str()) : (int)SVSDF_SHAPE_Polygon;
+      std::memcpy(cfg.poly_params, poly_params, sizeof(poly_params));
+      cfg.safety_hor = safety_hor; cfg.weight_p = weight_p; cfg.rho = rho;
+      std::memcpy(cfg.head_state, initState, sizeof(initState));
+      std::memcpy(cfg.tail_state, finalState, sizeof(finalState));
+      cfg.device = device; cfg.rank = rank; cfg.world_size = world_size;
+      cfg.polygon_nverts = (int)(polygon_xy.size() / 2);
+      cfg.polygon_xy = polygon_xy.empty() ? nullptr : polygon_xy.data();
+      ctx_ = svsdf_create(&cfg);
+      points_dirty_ = true;
+    }
+    if (ctx_ && points_dirty_) {
+      if (svsdf_set_points(ctx_, parallel_points.data(), (std::size_t)parallel_points_num) != SVSDF_OK) return nullptr;
+      points_dirty_ = false;
+    }
+    return ctx_;
+  }
+
+ private:
+  svsdf_ctx *ctx_ = nullptr;
+  bool points_dirty_ = true;
+};
+
+}  // namespace svsdf

@@ -1,0 +1,39 @@
+// Drives the C++ mirror (include/svsdf_traj_optimizer.hpp) exactly like the reference's
+// optimize_traj_lmbm drives TrajOptimizer: a raw lmbm_evaluate_t function pointer + void* instance.
+// Input (stdin): shape_inputdata safety_hor weight_p rho N P, then 9+9 state doubles, n x-doubles,
+// 3P point doubles.  Output: cost, cost_pos, cost_other, cost_total, then g[0..n).
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "svsdf_traj_optimizer.hpp"
+
+typedef double (*lmbm_evaluate_t)(void *instance, const double *x, double *g, const int n);  // lmbm.h:206-209
+
+int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "--host-only") {
+    // no GPU needed: registry lookup + MINCO helper through the same library
+    std::printf("%d %d\n", svsdf_shape_id_from_inputdata("shapes/sdHeart.obj"), svsdf_shape_id_from_inputdata("x/unknown.obj"));
+    return 0;
+  }
+  char name[256];
+  double sh, wp, rho;
+  int N, P;
+  if (std::scanf("%255s %lf %lf %lf %d %d", name, &sh, &wp, &rho, &N, &P) != 6) return 2;
+  double hs[9], ts[9];
+  for (double &v : hs) if (std::scanf("%lf", &v) != 1) return 2;
+  for (double &v : ts) if (std::scanf("%lf", &v) != 1) return 2;
+  const int n = 4 * N - 3;
+  std::vector<double> x(n), g(n), pts(3 * (size_t)P);
+  for (double &v : x) if (std::scanf("%lf", &v) != 1) return 2;
+  for (double &v : pts) if (std::scanf("%lf", &v) != 1) return 2;
+  svsdf::TrajOptimizerHip opt;
+  opt.inputdata = name; opt.safety_hor = sh; opt.weight_p = wp; opt.rho = rho; opt.device = 0;
+  opt.setConditions(hs, ts, N);
+  opt.setPoints(pts.data(), (size_t)P);
+  lmbm_evaluate_t eval = &svsdf::TrajOptimizerHip::costFunctionLmbmParallel;
+  const double f = eval(&opt, x.data(), g.data(), n);
+  std::printf("%.17g %.17g %.17g %.17g\n", f, opt.cost_pos, opt.cost_other, opt.cost_total);
+  for (int i = 0; i < n; ++i) std::printf("%.17g\n", g[i]);
+  return 0;
+}
