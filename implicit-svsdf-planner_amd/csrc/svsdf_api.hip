@@ -61,6 +61,9 @@ struct svsdf_ctx {
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
   int G = 4, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
+  int late_iter = 4, first_iters = 12, it_done = 0, G_seed = 8;
+  bool adaptive_iters = true;
+  double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
   // per-point / per-sub-query buffers
   double *d_seed_t = nullptr, *d_seed_min = nullptr, *d_sdf = nullptr, *d_t = nullptr;
@@ -73,6 +76,8 @@ struct svsdf_ctx {
   double *d_out = nullptr;        // [partial (19 * kMaxPieces + 1) | 8 x u64 stats]
   double *h_out = nullptr;        // pinned mirror
   int *d_nonfinite = nullptr;
+  int h_nonfinite = 0;
+  size_t e_end = 0;
 
   // profiling
   bool profile = false;  // per-launch HIP events (env SVSDF_PROFILE=1 or svsdf_set_profiling)
@@ -159,27 +164,32 @@ size_t next_event(svsdf_ctx *ctx) {
   }
 #endif
 
-// One argmin solve launch pair (k_seed + k_refine) over a query set on stream `st`.
-// max_queries bounds the (possibly device-side) query count and sizes the persistent grids.
+// Persistent-grid launchers.  max_queries bounds the (possibly device-side) query count.
 template <int S, int G>
-void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries,
-                     double *seed_t, double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
-                     int work_base) {
+void launch_seed_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, const SampleGen &sg, long long max_queries,
+                    double *seed_t, double *seed_min, BatchCtl *ctl, int work_idx) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
-  // seed: 256-thread persistent blocks, pose + chunk tables in LDS
-  const size_t seed_lds = (4 * (size_t)ctx->K + 4 * (size_t)((ctx->K + kChunk - 1) / kChunk)) * sizeof(double);
-  const unsigned seed_grid = (unsigned)std::min<long long>((lanes + kBlock - 1) / kBlock, 1024);
-  hipLaunchKernelGGL((k_seed<S, G>), dim3(seed_grid), dim3(kBlock), seed_lds, st, ctx->d_traj, d_tk, ctx->d_pose,
-                     ctx->d_chunks, ctx->sp, qs, seed_t, seed_min, ctx->prune, ctl, work_base);
-  // refine: small persistent blocks (fine-grained dynamic fetch), trajectory in LDS
+  // 256-thread persistent blocks, pose + chunk tables in LDS
+  const size_t lds = (4 * (size_t)ctx->K + 4 * (size_t)((ctx->K + kChunk - 1) / kChunk)) * sizeof(double);
+  const unsigned grid = (unsigned)std::min<long long>((lanes + kBlock - 1) / kBlock, 1024);
+  hipLaunchKernelGGL((k_seed<S, G>), dim3(grid), dim3(kBlock), lds, st, ctx->d_traj, d_tk, ctx->d_pose,
+                     ctx->d_chunks, ctx->sp, qs, sg, seed_t, seed_min, ctx->prune, ctl, work_idx);
+}
+
+template <int S, int G>
+void launch_refine_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries,
+                      const double *seed_t, const double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
+                      int work_idx) {
+  const long long lanes = std::max<long long>(max_queries * G, 64);
+  // small persistent blocks (fine-grained dynamic fetch), trajectory in LDS
   const int blk = ctx->block;
-  const size_t ref_lds = (size_t)traj_lds_doubles(ctx->N) * sizeof(double);
-  const unsigned ref_grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
+  const size_t lds = (size_t)traj_lds_doubles(ctx->N) * sizeof(double);
+  const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  hipLaunchKernelGGL((k_refine<S, G>), dim3(ref_grid), dim3(blk), ref_lds, st, ctx->d_traj, ctx->sp, qs, seed_t,
-                     seed_min, out_sdf, out_t, ctl, work_base + 1);
+  hipLaunchKernelGGL((k_refine<S, G>), dim3(grid), dim3(blk), lds, st, ctx->d_traj, ctx->sp, qs, seed_t, seed_min,
+                     out_sdf, out_t, ctl, work_idx);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -188,22 +198,36 @@ void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long lo
   ctx->stats.solve_launches++;
 }
 
+#define SVSDF_FOR_G(G, CALL) \
+  switch (G) { case 1: CALL(1); break; case 2: CALL(2); break; case 8: CALL(8); break; default: CALL(4); break; }
+
 template <int S>
-void launch_solve_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long max_queries,
-                    double *seed_t, double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
-                    int work_base) {
+void launch_seed_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, const SampleGen &sg, long long mq,
+                   double *seed_t, double *seed_min, BatchCtl *ctl, int work_idx) {
   switch (G) {
-    case 1: launch_solve_sg<S, 1>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
-    case 2: launch_solve_sg<S, 2>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
-    case 8: launch_solve_sg<S, 8>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
-    default: launch_solve_sg<S, 4>(ctx, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base); break;
+    case 1: launch_seed_sg<S, 1>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
+    case 4: launch_seed_sg<S, 4>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
+    case 16: launch_seed_sg<S, 16>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
+    default: launch_seed_sg<S, 8>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
   }
 }
+template <int S>
+void launch_refine_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, const double *seed_t,
+                     const double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl, int work_idx) {
+#define CALLG(GG) launch_refine_sg<S, GG>(ctx, st, qs, mq, seed_t, seed_min, out_sdf, out_t, ctl, work_idx)
+  SVSDF_FOR_G(G, CALLG)
+#undef CALLG
+}
 
-void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long max_queries,
-                  double *seed_t, double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
-                  int work_base) {
-#define CALL(S) launch_solve_s<S>(ctx, G, st, qs, max_queries, seed_t, seed_min, out_sdf, out_t, ctl, work_base)
+void launch_seed(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, const SampleGen &sg, long long mq,
+                 double *seed_t, double *seed_min, BatchCtl *ctl, int work_idx) {
+#define CALL(S) launch_seed_s<S>(ctx, G, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx)
+  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+}
+void launch_refine(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, const double *seed_t,
+                   const double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl, int work_idx) {
+#define CALL(S) launch_refine_s<S>(ctx, G, st, qs, mq, seed_t, seed_min, out_sdf, out_t, ctl, work_idx)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
 }
@@ -269,8 +293,48 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   return SVSDF_OK;
 }
 
-// samples per GSIP round: 2, 6, 18, 21, 21, ... (+1 for accumulated-angle rounding), SWM:60-71,105-110
-const int kRoundSlots[kMaxRounds] = {3, 7, 19, 22, 22, 22, 22, 22, 22};
+
+int join_batches(svsdf_ctx *ctx) {
+  for (int b = 0; b < ctx->nbatch; ++b) {
+    HIPCHK(hipEventRecord(ctx->ev_done[b], ctx->bstream[b]));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
+  }
+  HIPCHK(hipGetLastError());
+  return SVSDF_OK;
+}
+
+// GSIP iterations [it0, it1) for every batch: seed the freshly emitted circle samples, select
+// the samples worth solving (upper-bound selection), solve them, close / extend the rounds.
+void enqueue_iterations(svsdf_ctx *ctx, int it0, int it1) {
+  for (int it = it0; it < it1; ++it) {
+    for (int b = 0; b < ctx->nbatch; ++b) {
+      hipStream_t st = ctx->bstream[b];
+      BatchCtl *ctl = ctx->d_ctl + b;
+      const long long cap = (long long)ctx->bcount[b] * kMaxSlots;
+      const size_t off = (size_t)ctx->bstart[b] * kMaxSlots;
+      const int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
+      QuerySet qseed{};
+      qseed.qx = ctx->gs.sqx; qseed.qy = ctx->gs.sqy; qseed.count_ptr = &ctl->n_seed[it];
+      qseed.slots = ctx->gs.seedl[it & 1] + off; qseed.n_outer = 1;
+      SampleGen sg{};
+      sg.cx = ctx->d_px; sg.cy = ctx->d_py; sg.pt = ctx->gs.pt; sg.r = ctx->gs.r; sg.theta0 = ctx->gs.theta0;
+      sg.theta_res = ctx->gs.theta_res; sg.sqx = ctx->gs.sqx; sg.sqy = ctx->gs.sqy; sg.sqth = ctx->gs.sqth;
+      sg.sq_sdf = ctx->gs.sq_sdf; sg.stride = ctx->P;
+      launch_seed(ctx, ctx->G_seed, st, qseed, sg, cap, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctl, 2 * (it + 1));
+      const unsigned grid = (unsigned)std::min<long long>(((long long)ctx->bcount[b] + kBlock - 1) / kBlock, 1024);
+      hipLaunchKernelGGL(k_select, dim3(grid), dim3(kBlock), 0, st, ctx->gs, ctx->d_sq_seed_min, ctx->P, it,
+                         ctx->select_delta, ctl);
+      QuerySet qsol = qseed;
+      qsol.count_ptr = &ctl->n_solve[it];
+      qsol.slots = ctx->gs.solve[it & 1] + off;
+      launch_refine(ctx, G, st, qsol, cap, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl,
+                    2 * (it + 1) + 1);
+      hipLaunchKernelGGL(k_gsip, dim3(grid), dim3(kBlock), 0, st, ctx->d_px, ctx->d_py, ctx->gs,
+                         ctx->d_sq_seed_min, ctx->P, it, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx,
+                         ctx->d_res_gy, ctl);
+    }
+  }
+}
 
 // Enqueue the device pipeline up to the per-point results of getTrueSDFofSweptVolume (res_*).
 // No host synchronisation: batches run on their own streams, joined back onto ctx->stream.
@@ -296,54 +360,73 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     QuerySet qm{};
     qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
     qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
-    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctl, 0);
+    launch_seed(ctx, ctx->G_seed, st, qm, SampleGen{}, ctx->bcount[b], ctx->d_seed_t, ctx->d_seed_min, ctl, 0);
+    launch_refine(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctl, 1);
     launch_classify(ctx, st, b);
   }
-  for (int r = 0; r < kMaxRounds; ++r) {
-    for (int b = 0; b < ctx->nbatch; ++b) {
-      hipStream_t st = ctx->bstream[b];
-      BatchCtl *ctl = ctx->d_ctl + b;
-      QuerySet qsub{};
-      qsub.qx = ctx->gs.sqx; qsub.qy = ctx->gs.sqy; qsub.stride = ctx->P;
-      qsub.count_ptr = &ctl->n_active[r]; qsub.count_fixed = 0;
-      qsub.list = ctx->gs.list[r & 1] + ctx->bstart[b]; qsub.base = ctx->bstart[b]; qsub.n_outer = kRoundSlots[r];
-      const int G = (r >= 4) ? ctx->G_late : ctx->G;
-      launch_solve(ctx, G, st, qsub, (long long)ctx->bcount[b] * kRoundSlots[r], ctx->d_sq_seed_t,
-                   ctx->d_sq_seed_min, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl, 2 * (r + 1));
-      const unsigned grid = (unsigned)std::min<long long>(((long long)ctx->bcount[b] + kBlock - 1) / kBlock, 1024);
-      hipLaunchKernelGGL(k_gsip, dim3(grid), dim3(kBlock), 0, st, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, r,
-                         ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctl);
+  enqueue_iterations(ctx, 0, ctx->first_iters);
+  ctx->it_done = ctx->first_iters;
+  return join_batches(ctx);
+}
+
+// assemble + reduce + k_finish on the main stream, one D2H of [partial | counters], sync.
+int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
+  const int N = ctx->N;
+  if (with_partial) {
+    const unsigned grid = (unsigned)std::min<size_t>((ctx->P + kBlock - 1) / kBlock, 512);
+    const size_t plen = 19 * (size_t)N + 1;
+    if ((size_t)grid * plen > ctx->block_partials_cap) {
+      int rc = dev_alloc(ctx, &ctx->d_block_partials, (size_t)grid * plen);
+      if (rc) return rc;
+      ctx->block_partials_cap = (size_t)grid * plen;
     }
+    const size_t lds = ((size_t)traj_lds_doubles(N) + plen) * sizeof(double);
+    hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
+                       (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
+                       ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite);
+    hipLaunchKernelGGL(k_final, dim3((unsigned)plen), dim3(64), 0, ctx->stream, ctx->d_block_partials, (int)grid,
+                       ctx->d_sums);
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->d_sums, 0, kOutPartial * sizeof(double), ctx->stream));
   }
-  for (int b = 0; b < ctx->nbatch; ++b) {
-    HIPCHK(hipEventRecord(ctx->ev_done[b], ctx->bstream[b]));
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
-  }
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
+                     ctx->nbatch, ctx->it_done, reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
+  ctx->e_end = next_event(ctx);
+  (void)hipEventRecord(ctx->ev_pool[ctx->e_end], ctx->stream);
+  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&ctx->h_nonfinite, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return SVSDF_OK;
 }
 
-// k_finish gathers partial + counters into d_out; one D2H copy brings everything to the host.
+// Finish an evaluation: reduce, read back, and -- rare slow path -- run more GSIP iterations when
+// some points needed more than `first_iters` (rounds + supplementary solves), then reduce again.
 int finish(svsdf_ctx *ctx, bool with_partial) {
-  const int N = ctx->N;
-  if (!with_partial) HIPCHK(hipMemsetAsync(ctx->d_sums, 0, kOutPartial * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
-                     ctx->nbatch, reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
-  const size_t e_end = next_event(ctx);
-  (void)hipEventRecord(ctx->ev_pool[e_end], ctx->stream);
-  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  int nonfinite = 0;
-  HIPCHK(hipMemcpyAsync(&nonfinite, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipGetLastError());
+  int rc = reduce_and_read(ctx, with_partial);
+  if (rc) return rc;
   const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out + kOutPartial);
+  while (st[5] > 0 && ctx->it_done < kMaxIter) {
+    const int it1 = std::min(ctx->it_done + 4, (int)kMaxIter);
+    enqueue_iterations(ctx, ctx->it_done, it1);
+    ctx->it_done = it1;
+    if ((rc = join_batches(ctx))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), ctx->stream));
+    if ((rc = reduce_and_read(ctx, with_partial))) return rc;
+  }
+  if (st[5] > 0) return fail(ctx, SVSDF_ERR_INVALID, "GSIP iterations exhausted (internal limit)");
   ctx->stats.solves = st[0];
   ctx->stats.sdf_evals = st[1];
   ctx->stats.scan_evals = st[2];
   ctx->stats.interior_points = st[3];
+  ctx->stats.gsip_samples = st[6];
+  ctx->stats.gsip_iterations = (unsigned)st[7];
+  // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
+  // covers an underestimate
+  if (ctx->adaptive_iters) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
   if (ctx->profile) {
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[e_end]);
+    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
     ctx->stats.device_ms = ms;
     double sum = 0.0;
     for (const auto &pr : ctx->refine_events) {
@@ -352,7 +435,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
     }
     ctx->stats.solve_ms = sum;
   }
-  if (nonfinite || st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
+  if (ctx->h_nonfinite || st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
 }
 
@@ -360,19 +443,6 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
 int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   int rc = enqueue_queries(ctx, N, coeffs, T);
   if (rc) return rc;
-  const unsigned grid = (unsigned)std::min<size_t>((ctx->P + kBlock - 1) / kBlock, 512);
-  const size_t plen = 19 * (size_t)N + 1;
-  if ((size_t)grid * plen > ctx->block_partials_cap) {
-    rc = dev_alloc(ctx, &ctx->d_block_partials, (size_t)grid * plen);
-    if (rc) return rc;
-    ctx->block_partials_cap = (size_t)grid * plen;
-  }
-  const size_t lds = ((size_t)traj_lds_doubles(N) + plen) * sizeof(double);
-  hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
-                     (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                     ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite);
-  hipLaunchKernelGGL(k_final, dim3((unsigned)plen), dim3(64), 0, ctx->stream, ctx->d_block_partials, (int)grid,
-                     ctx->d_sums);
   return finish(ctx, true);
 }
 
@@ -400,8 +470,13 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.theta_res, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.iter, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.nsamp, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.supp, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[0], P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[1], P))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dev_alloc(ctx, &ctx->gs.solve[k], P * kMaxSlots))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->gs.seedl[k], P * kMaxSlots))) return rc;
+  }
   const size_t S = P * kMaxSlots;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqx, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqy, S))) return rc;
@@ -452,7 +527,7 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   HIPCHK(hipDeviceSynchronize());
   shard_plan(xyz, P, ctx->cfg.rank, ctx->cfg.world_size, ctx->cfg.flags, ctx->shard_idx);
   const size_t Ps = ctx->shard_idx.size();
-  if (Ps > 0x3fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard");
+  if (Ps * kMaxSlots > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard (max ~89M)");
   ctx->P = Ps;
   int rc = alloc_point_buffers(ctx, Ps);
   if (rc) return rc;
@@ -465,7 +540,7 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
   // batches: contiguous ranges of the sorted shard, pipelined on separate streams
-  int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;
+  int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;  // multi-stream batches (SVSDF_BATCHES) measured inconsistent across boxes
   nb = std::max(1, std::min(nb, kMaxBatches));
   ctx->nbatch = nb;
   std::vector<BatchCtl> hc(kMaxBatches);
@@ -583,6 +658,10 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
+  if (const char *e = std::getenv("SVSDF_G_SEED")) { const int g = std::atoi(e); if (g == 1 || g == 4 || g == 8 || g == 16) ctx->G_seed = g; }
+  if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) ctx->select_delta = std::atof(e);
+  if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
+  if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
   for (int b = 0; b < kMaxBatches; ++b) {
     if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||
@@ -624,7 +703,7 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,
                   ctx->d_res_gx, ctx->d_res_gy, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctx->gs.pt, ctx->gs.r,
                   ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.list[0],
-                  ctx->gs.list[1], ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth, ctx->gs.sq_sdf, ctx->gs.sq_t,
+                  ctx->gs.list[1], ctx->gs.supp, ctx->gs.solve[0], ctx->gs.solve[1], ctx->gs.seedl[0], ctx->gs.seedl[1], ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth, ctx->gs.sq_sdf, ctx->gs.sq_t,
                   ctx->d_ctl, ctx->d_block_partials, ctx->d_sums, ctx->d_out, ctx->d_nonfinite};
   for (void *p : bufs)
     if (p) (void)hipFree(p);

@@ -29,7 +29,11 @@ constexpr int kMaxSlots = 24;   // GSIP samples per round: 2, 6, 18, 21, 21, ...
 constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
 constexpr int kBlock = 256;
 constexpr int kMaxBatches = 8;
-constexpr int kWorkCounters = 2 * (kMaxRounds + 1);  // one per (seed|refine) launch of a batch
+// GSIP iterations: a round normally takes one iteration, plus one supplementary iteration when
+// the upper-bound selection (k_select / k_gsip) has to solve more samples of the same round.
+constexpr int kMaxIter = 24;
+constexpr int kWorkCounters = 2 * (kMaxIter + 1);  // one per (seed|refine) launch of a batch
+constexpr double kUnsolved = -1e300;               // sq_sdf marker: sample not (yet) solved
 
 // Trajectory as the device sees it (global memory; staged into LDS by each block).
 struct TrajDev {
@@ -53,7 +57,9 @@ struct Chunk { double cx, cy, rb, pad; };
 // every evaluation, start/count are written by the host once per point upload).
 struct BatchCtl {
   int start, count;               // points [start, start + count) of the sorted shard
-  int n_active[kMaxRounds + 1];   // [r] = GSIP points entering round r; [0] = interior points
+  int n_active[kMaxIter + 2];     // [i] = GSIP points entering iteration i; [0] = interior points
+  int n_solve[kMaxIter + 2];      // [i] = sample solves requested for iteration i
+  int n_seed[kMaxIter + 2];       // [i] = new samples to seed in iteration i
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
   int pad;
@@ -158,7 +164,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K,
   const double *coeffs = in, *T = in + 18 * N, *tk = in + 19 * N;
   for (int b = threadIdx.x; b < nbatch; b += blockDim.x) {
     BatchCtl &c = ctl[b];
-    for (int r = 0; r <= kMaxRounds; ++r) c.n_active[r] = 0;
+    for (int r = 0; r < kMaxIter + 2; ++r) { c.n_active[r] = 0; c.n_solve[r] = 0; c.n_seed[r] = 0; }
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
     c.nonfinite = 0;
     c.stat_solves = 0ull; c.stat_evals = 0ull; c.stat_scan = 0ull;
@@ -234,16 +240,32 @@ struct QuerySet {
   const int *list;        // compacted active list (may be null)
   int base;
   int n_outer;
+  const int *slots;       // explicit slot list (n = *count_ptr entries, overrides the rest) or null
+  const int *skip;        // per-entry skip flags indexed by base + a (may be null)
+};
+
+// GSIP circle samples are materialised by the seed kernel itself (one lane group per sample):
+// sample j of interior point ia sits at centre + r (cos th_j, sin th_j), th_j = th0 + j*th_res
+// by repeated addition (SampleSet2D::getElements / getElementPos, SWM:36-39, 60-71).
+struct SampleGen {
+  const double *cx, *cy;      // main points
+  const int *pt;              // interior -> main point index
+  const double *r, *theta0, *theta_res;
+  double *sqx, *sqy, *sqth, *sq_sdf;
+  size_t stride;
 };
 
 __device__ __forceinline__ long long qs_total(const QuerySet &qs, int &n) {
   n = qs.count_ptr ? *qs.count_ptr : qs.count_fixed;
-  return (long long)n * qs.n_outer;
+  return qs.slots ? (long long)n : (long long)n * qs.n_outer;
 }
-__device__ __forceinline__ size_t qs_slot(const QuerySet &qs, int n, long long q) {
+// returns false when the query is to be skipped
+__device__ __forceinline__ bool qs_slot(const QuerySet &qs, int n, long long q, size_t &slot) {
+  if (qs.slots) { slot = (size_t)qs.slots[q]; return true; }
   const int e = (int)(q % n), j = (int)(q / n);
   const int a = qs.list ? qs.list[e] : e;
-  return (size_t)j * qs.stride + (size_t)qs.base + (size_t)a;
+  slot = (size_t)j * qs.stride + (size_t)qs.base + (size_t)a;
+  return !(qs.skip && qs.skip[qs.base + a]);
 }
 
 // G lanes cooperate on one query (64/G queries per wave).
@@ -297,12 +319,13 @@ __device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wav
 template <int SHAPE, int G>
 __global__ void __launch_bounds__(kBlock)
 k_seed(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
-       const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ seed_t,
-       double *__restrict__ seed_min, int prune, BatchCtl *__restrict__ ctl, int work_idx) {
+       const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, SampleGen sg,
+       double *__restrict__ seed_t, double *__restrict__ seed_min, int prune,
+       BatchCtl *__restrict__ ctl, int work_idx) {
   extern __shared__ double seed_lds[];
   int n;
   const long long total = qs_total(qs, n);
-  if (total <= 0) return;
+  if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
   Pose *pose = reinterpret_cast<Pose *>(seed_lds);
@@ -317,20 +340,42 @@ k_seed(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   const int li = Grp<G>::li();
   unsigned n_scan = 0;
   long long gq_first = 0;
-  constexpr int kSeedFetch = 8;  // the scan of one query is short: take 8 wave-loads per atomic
+  // the scan of one query is short: take up to 8 wave-loads per atomic, fewer when the launch
+  // has little work per resident wave (keeps every wave busy instead of a few waves for long)
+  const long long per_wave = total / ((long long)gridDim.x * (blockDim.x / 64) * (64 / G));
+  const int nfetch = (int)(per_wave < 1 ? 1 : (per_wave > 8 ? 8 : per_wave));
   for (int guard = 0; guard < (1 << 24); ++guard) {
-    long long wave_base;
-    gq_first = fetch_work<G, kSeedFetch>(&ctl->work[work_idx], wave_base);
+    long long wave_base = 0;
+    {
+      unsigned base = 0;
+      if ((threadIdx.x & 63) == 0) base = atomicAdd(&ctl->work[work_idx], (unsigned)(nfetch * 64 / G));
+      base = __builtin_amdgcn_readfirstlane(base);
+      wave_base = (long long)base;
+      gq_first = wave_base + (long long)((threadIdx.x & 63) / G);
+    }
     if (wave_base >= total) break;
-    for (int sub = 0; sub < kSeedFetch; ++sub) {
+    for (int sub = 0; sub < nfetch; ++sub) {
     const long long gq = gq_first + (long long)sub * (64 / G);
     double px = 0.0, py = 0.0;
     size_t slot = 0;
     bool live = gq < total;
+    if (live) live = qs_slot(qs, n, gq, slot);
     if (live) {
-      slot = qs_slot(qs, n, gq);
-      px = qs.qx[slot]; py = qs.qy[slot];
-      live = (px == px);  // NaN marks an unused slot (whole group)
+      if (sg.sqx) {  // materialise the circle sample (slot = j * stride + ia)
+        const int j = (int)(slot / sg.stride);
+        const size_t ia = slot - (size_t)j * sg.stride;
+        double theta = sg.theta0[ia];
+        const double theta_res = sg.theta_res[ia];
+        for (int q = 0; q < j; ++q) theta += theta_res;
+        const double r = sg.r[ia];
+        const int i = sg.pt[ia];
+        px = sg.cx[i] + 1.0 * r * cos(theta);
+        py = sg.cy[i] + 1.0 * r * sin(theta);
+        if (li == 0) { sg.sqx[slot] = px; sg.sqy[slot] = py; sg.sqth[slot] = theta; sg.sq_sdf[slot] = kUnsolved; }
+      } else {
+        px = qs.qx[slot]; py = qs.qy[slot];
+        live = (px == px);  // NaN marks an unused slot (whole group)
+      }
     }
     if (live) {
     double best_d = 1e9;   // min_dis initial value (SWM:545)
@@ -415,7 +460,7 @@ k_refine(const TrajDev *__restrict__ trg, ShapeParams sp, QuerySet qs,
   extern __shared__ double refine_lds[];
   int n;
   const long long total = qs_total(qs, n);
-  if (total <= 0) return;
+  if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
   const TrajL tr = stage_traj(trg, refine_lds);
   const int li = Grp<G>::li();
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -427,8 +472,8 @@ k_refine(const TrajDev *__restrict__ trg, ShapeParams sp, QuerySet qs,
     double px = 0.0, py = 0.0;
     size_t slot = 0;
     bool live = gq < total;
+    if (live) live = qs_slot(qs, n, gq, slot);
     if (live) {
-      slot = qs_slot(qs, n, gq);
       px = qs.qx[slot]; py = qs.qy[slot];
       live = (px == px);
     }
@@ -540,27 +585,24 @@ struct GsipState {
   double *theta_res;
   int *iter;        // 1..9
   int *nsamp;       // samples emitted for the current round
+  int *supp;        // 1: the point waits for supplementary sample solves of its current round
   int *list[2];     // ping-pong compacted lists of still-active interior indices
+  int *solve[2];    // ping-pong lists of sample slots to solve (capacity kMaxSlots per point)
+  int *seedl[2];    // ping-pong lists of freshly emitted sample slots to seed
   // sub-query slots [j * stride + batch start + a]
   double *sqx, *sqy, *sqth, *sq_sdf, *sq_t;
 };
 
 // SampleSet2D::getElements + getElementPos (SWM:36-39, 60-71) for the single ring rk = 1.0.
-__device__ __forceinline__ int emit_samples(const GsipState &gs, size_t ia, size_t stride, double cx,
-                                            double cy, double r, double theta0, double theta_res) {
+// Number of samples of a round (the theta loop of SampleSet2D::getElements, SWM:60-71) and their
+// slots pushed to the seed list; the seed kernel materialises the positions.
+__device__ __forceinline__ int emit_samples(size_t ia, size_t stride, double theta0, double theta_res,
+                                            int *__restrict__ seed_list, int *__restrict__ seed_count) {
   int n = 0;
-  for (double theta = theta0; theta < theta0 + 2 * kPI; theta += theta_res) {
-    if (n < kMaxSlots) {
-      const size_t s = (size_t)n * stride + ia;
-      gs.sqx[s] = cx + 1.0 * r * cos(theta);
-      gs.sqy[s] = cy + 1.0 * r * sin(theta);
-      gs.sqth[s] = theta;
-    }
-    ++n;
-  }
+  for (double theta = theta0; theta < theta0 + 2 * kPI; theta += theta_res) ++n;
   n = n < kMaxSlots ? n : kMaxSlots;
-  const double nan = __longlong_as_double(0x7ff8000000000000ll);
-  for (int j = n; j < kMaxSlots; ++j) gs.sqx[(size_t)j * stride + ia] = nan;
+  int pos = atomicAdd(seed_count, n);
+  for (int j = 0; j < n; ++j) seed_list[pos++] = (int)((size_t)j * stride + ia);
   return n;
 }
 
@@ -622,22 +664,61 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
     gs.theta0[ia] = theta0;
     gs.theta_res[ia] = theta_res;
     gs.iter[ia] = 1;
+    gs.supp[ia] = 0;
     gs.list[0][ia] = a;
-    gs.nsamp[ia] = emit_samples(gs, ia, stride, px, py, r0, theta0, theta_res);
+    gs.nsamp[ia] = emit_samples(ia, stride, theta0, theta_res, gs.seedl[0] + (size_t)start * kMaxSlots,
+                                &ctl->n_seed[0]);
     res_t[i] = ts;  // real_t_star fallback
   }
 }
 
-// One GSIP round per still-active interior point (SWM:965-1009) and the final assembly
-// (SWM:1011-1017).  Points that continue are appended to the next round's compacted list.
+// ---------------------------------------------------------------------------------------------
+// Upper-bound selection of the GSIP samples (exact).  A round only uses the arg-max sample:
+// max_g, its t* and its angle (SWM:975-990).  Every sample's solved value is bounded above by
+// its layer-1 seed value U_j: layers 2-4 only lower min_dis, the descent starts at
+// f(time_seed) == min_dis and only accepts strict decreases.  So after solving a subset whose
+// best value is g*, any sample with U_j < g* can neither be nor tie with the maximum and need not
+// be solved.  k_select requests the samples within `delta` of the best bound; k_gsip requests the
+// rest of {U_j >= g*} (one supplementary iteration, rarely non-empty) before it closes the round.
+// ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_gsip(const double *__restrict__ px_, const double *__restrict__ py_, GsipState gs, size_t stride,
-       int round, double *__restrict__ res_sdf, double *__restrict__ res_t,
-       double *__restrict__ res_gx, double *__restrict__ res_gy, BatchCtl *__restrict__ ctl) {
-  const int n_act = ctl->n_active[round];
+k_select(GsipState gs, const double *__restrict__ seed_min, size_t stride, int it, double delta,
+         BatchCtl *__restrict__ ctl) {
+  const int n_act = ctl->n_active[it];
   const int start = ctl->start;
-  const int *cur = gs.list[round & 1] + start;
-  int *nxt = gs.list[(round + 1) & 1] + start;
+  const int *cur = gs.list[it & 1] + start;
+  int *out = gs.solve[it & 1] + (size_t)start * kMaxSlots;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_act; e += gridDim.x * blockDim.x) {
+    const int a = cur[e];
+    const size_t ia = (size_t)start + a;
+    if (gs.supp[ia]) continue;  // its supplementary solves were requested by k_gsip
+    const int n = gs.nsamp[ia];
+    double umax = -1e300;
+    for (int j = 0; j < n; ++j) umax = fmax(umax, seed_min[(size_t)j * stride + ia]);
+    const double thr = umax - delta;
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) cnt += (seed_min[(size_t)j * stride + ia] >= thr) ? 1 : 0;
+    int pos = atomicAdd(&ctl->n_solve[it], cnt);
+    for (int j = 0; j < n; ++j) {
+      const size_t sl = (size_t)j * stride + ia;
+      if (seed_min[sl] >= thr) out[pos++] = (int)sl;
+    }
+  }
+}
+
+// One GSIP iteration per still-active interior point: close the round (SWM:965-1009, final
+// assembly SWM:1011-1017) or request supplementary solves.  Points that continue are appended to
+// the next iteration's compacted list.
+__global__ void __launch_bounds__(kBlock)
+k_gsip(const double *__restrict__ px_, const double *__restrict__ py_, GsipState gs,
+       const double *__restrict__ seed_min, size_t stride, int it, double *__restrict__ res_sdf,
+       double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
+       BatchCtl *__restrict__ ctl) {
+  const int n_act = ctl->n_active[it];
+  const int start = ctl->start;
+  const int *cur = gs.list[it & 1] + start;
+  int *nxt = gs.list[(it + 1) & 1] + start;
+  int *solve_nxt = gs.solve[(it + 1) & 1] + (size_t)start * kMaxSlots;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_act; e += gridDim.x * blockDim.x) {
     const int a = cur[e];
     const size_t ia = (size_t)start + a;
@@ -646,11 +727,28 @@ k_gsip(const double *__restrict__ px_, const double *__restrict__ py_, GsipState
     double max_g = -100000;
     double real_t = res_t[i], star_th = 0.0;
     const int n = gs.nsamp[ia];
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < n; ++j) {  // solved samples only; unsolved ones carry kUnsolved
       const size_t s = (size_t)j * stride + ia;
       const double cur_g = gs.sq_sdf[s];
       if (cur_g > max_g) { max_g = cur_g; real_t = gs.sq_t[s]; star_th = gs.sqth[s]; }
     }
+    // unsolved samples that could still reach max_g
+    int more = 0;
+    for (int j = 0; j < n; ++j) {
+      const size_t s = (size_t)j * stride + ia;
+      more += (gs.sq_sdf[s] == kUnsolved && seed_min[s] >= max_g) ? 1 : 0;
+    }
+    if (more > 0) {
+      int pos = atomicAdd(&ctl->n_solve[it + 1], more);
+      for (int j = 0; j < n; ++j) {
+        const size_t s = (size_t)j * stride + ia;
+        if (gs.sq_sdf[s] == kUnsolved && seed_min[s] >= max_g) solve_nxt[pos++] = (int)s;
+      }
+      gs.supp[ia] = 1;
+      nxt[atomicAdd(&ctl->n_active[it + 1], 1)] = a;
+      continue;
+    }
+    gs.supp[ia] = 0;
     const double r_star = gs.r[ia] - max_g;
     const int iter = gs.iter[ia];
     if (iter > 8 || fabs(max_g) < 0.1) {
@@ -670,9 +768,9 @@ k_gsip(const double *__restrict__ px_, const double *__restrict__ py_, GsipState
     gs.theta0[ia] = star_th;
     gs.iter[ia] = iter + 1;
     res_t[i] = real_t;
-    gs.nsamp[ia] = emit_samples(gs, ia, stride, cx, cy, r_star, star_th, theta_res);
-    const int pos = atomicAdd(&ctl->n_active[round + 1], 1);
-    nxt[pos] = a;
+    gs.nsamp[ia] = emit_samples(ia, stride, star_th, theta_res, gs.seedl[(it + 1) & 1] + (size_t)start * kMaxSlots,
+                                &ctl->n_seed[it + 1]);
+    nxt[atomicAdd(&ctl->n_active[it + 1], 1)] = a;
   }
 }
 
@@ -780,18 +878,24 @@ k_final(const double *__restrict__ block_partials, int nblocks, double *__restri
 // partial = [cost, gradC (18N), gradT (N)] with gradT[j] = sum_{i > j} hist[i] (BEO:859-862);
 // also gathers the per-batch counters.
 __global__ void k_finish(const double *__restrict__ sums, int N, double *__restrict__ partial,
-                         const BatchCtl *__restrict__ ctl, int nbatch,
+                         const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
                          unsigned long long *__restrict__ stats_out) {
   for (int k = threadIdx.x; k <= 18 * N; k += blockDim.x) partial[k] = sums[k];
   if (threadIdx.x == 0) {
     double suf = 0.0;
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
-    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = 0;
+    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = 0, rem = 0, seeded = 0, iters = 0;
     for (int b = 0; b < nbatch; ++b) {
       so += ctl[b].stat_solves; ev += ctl[b].stat_evals; sc += ctl[b].stat_scan;
       in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
+      rem += (unsigned long long)ctl[b].n_active[it_end];   // > 0: more iterations are needed
+      for (int i = 0; i <= it_end; ++i) {
+        seeded += (unsigned long long)ctl[b].n_seed[i];
+        if (ctl[b].n_active[i] > 0 && (unsigned long long)(i + 1) > iters) iters = (unsigned long long)(i + 1);
+      }
     }
     stats_out[0] = so; stats_out[1] = ev; stats_out[2] = sc; stats_out[3] = in; stats_out[4] = nf;
+    stats_out[5] = rem; stats_out[6] = seeded; stats_out[7] = iters;
   }
 }
 

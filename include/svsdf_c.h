@@ -166,12 +166,14 @@ int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double
 typedef struct svsdf_stats {
   unsigned long long points;          /* main queries in this shard */
   unsigned long long interior_points; /* points that entered the GSIP loop */
-  unsigned long long solves;          /* argmin solves (main + GSIP sub-queries) */
+  unsigned long long solves;          /* argmin solves executed (main + selected GSIP samples) */
+  unsigned long long gsip_samples;    /* GSIP circle samples emitted (the reference solves all of them) */
   unsigned long long sdf_evals;       /* SDF-at-time evaluations executed on the device */
   unsigned long long scan_evals;      /* of which layer-1 table evaluations */
   double device_ms;                   /* HIP-event time of the whole device pipeline (profiling on) */
   double solve_ms;                    /* HIP-event time summed over the k_refine launches (profiling on) */
   unsigned int solve_launches;        /* k_refine launches of the last evaluation */
+  unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 /* Per-launch HIP-event timing of the dominant (argmin refine) kernel on the library's own

@@ -54,7 +54,9 @@ def test_per_point_queries_match_oracle(built, config, P):
     st = ctx.stats()
     cnt = o.counters()
     assert st["interior_points"] == cnt["interior_points"]
-    assert st["solves"] == cnt["solves"]
+    # the reference solves every GSIP circle sample; the upper-bound selection solves a subset
+    assert st["gsip_samples"] + P == cnt["solves"]
+    assert P < st["solves"] <= cnt["solves"]
 
 
 @pytest.mark.parametrize("config,P,N", [("C1", 4000, None), ("C2", 3000, None), ("C3", 2000, None),

@@ -48,7 +48,9 @@ def test_c2_full_size_solver_variants_bit_identical(c2):
             c.close()
             return out, st
         return _with_env(env, go)
-    ref, st_ref = run(dict(SVSDF_G=1, SVSDF_G_LATE=1, SVSDF_PRUNE=0, SVSDF_BATCHES=1))
+    # reference configuration: full scan, one lane per query, every GSIP sample solved
+    ref, st_ref = run(dict(SVSDF_G=1, SVSDF_G_LATE=1, SVSDF_PRUNE=0, SVSDF_BATCHES=1, SVSDF_SELECT_DELTA=1e9))
+    assert st_ref["solves"] == st_ref["gsip_samples"] + 100000
     assert st_ref["scan_evals"] == st_ref["solves"] * 267          # K = floor(40 / 0.15) + 1
     for env in (dict(SVSDF_G=4, SVSDF_G_LATE=8, SVSDF_PRUNE=1, SVSDF_BATCHES=1),
                 dict(SVSDF_G=2, SVSDF_G_LATE=2, SVSDF_PRUNE=1, SVSDF_BATCHES=4),
@@ -56,8 +58,9 @@ def test_c2_full_size_solver_variants_bit_identical(c2):
         out, st = run(env)
         for a, b in zip(out, ref):
             assert np.array_equal(a, b), env
-        assert st["solves"] == st_ref["solves"] and st["interior_points"] == st_ref["interior_points"]
+        assert st["gsip_samples"] == st_ref["gsip_samples"] and st["interior_points"] == st_ref["interior_points"]
         assert st["scan_evals"] < 0.2 * st_ref["scan_evals"]
+        assert st["solves"] < 0.6 * st_ref["solves"]
 
 
 def test_c2_full_size_determinism_and_shard_additivity(c2):
