@@ -147,7 +147,7 @@ def main():
         return
     ms_per_step = 1e3 * elapsed / a.steps
     value = P_total * a.steps / elapsed
-    # dominant kernel = k_refine; rank-0 HIP-event time on the library's own streams
+    # dominant kernel = k_solve; rank-0 HIP-event time on the library's own streams
     solve_ms_step = solve_ms / prof_steps
     shard = ctx.num_points()
     ach_gbs = BYTES_PER_POINT * shard / (solve_ms_step * 1e-3) / 1e9
@@ -170,7 +170,7 @@ def main():
                    "argmin_solves_per_point": solves_all / a.steps / P_total,
                    "gsip_samples_per_point_rank0": samples / a.steps / max(ctx.num_points(), 1),
                    "parallelism": f"points striped over {world} GPU(s), 1 all-reduce of {19 * N + 1} f64"},
-        "roofline": {"bound": "hbm", "kernel": "k_refine (argmin over t: scan layers 2-4 + descent; all launches of one evaluation)",
+        "roofline": {"bound": "hbm", "kernel": "k_solve (argmin over t: pruned table scan + scan layers 2-4 + descent; all launches of one evaluation)",
                      "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_unit": "bytes per evaluation (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",

@@ -61,14 +61,13 @@ struct svsdf_ctx {
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
   int G = 4, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
-  int late_iter = 4, first_iters = 12, it_done = 0, G_seed = 8;
+  int late_iter = 4, first_iters = 12, it_done = 0, U = 1;
   bool adaptive_iters = true;
   double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
   // per-point / per-sub-query buffers
-  double *d_seed_t = nullptr, *d_seed_min = nullptr, *d_sdf = nullptr, *d_t = nullptr;
+  double *d_sdf = nullptr, *d_t = nullptr;
   double *d_res_sdf = nullptr, *d_res_t = nullptr, *d_res_gx = nullptr, *d_res_gy = nullptr;
-  double *d_sq_seed_t = nullptr, *d_sq_seed_min = nullptr;
   GsipState gs{};
   double *d_block_partials = nullptr;
   size_t block_partials_cap = 0;  // doubles
@@ -164,32 +163,24 @@ size_t next_event(svsdf_ctx *ctx) {
   }
 #endif
 
-// Persistent-grid launchers.  max_queries bounds the (possibly device-side) query count.
-template <int S, int G>
-void launch_seed_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, const SampleGen &sg, long long max_queries,
-                    double *seed_t, double *seed_min, BatchCtl *ctl, int work_idx) {
-  const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
-  const long long lanes = std::max<long long>(max_queries * G, 64);
-  // 256-thread persistent blocks, pose + chunk tables in LDS
-  const size_t lds = (4 * (size_t)ctx->K + 4 * (size_t)((ctx->K + kChunk - 1) / kChunk)) * sizeof(double);
-  const unsigned grid = (unsigned)std::min<long long>((lanes + kBlock - 1) / kBlock, 1024);
-  hipLaunchKernelGGL((k_seed<S, G>), dim3(grid), dim3(kBlock), lds, st, ctx->d_traj, d_tk, ctx->d_pose,
-                     ctx->d_chunks, ctx->sp, qs, sg, seed_t, seed_min, ctx->prune, ctl, work_idx);
+// Persistent-grid launcher of the argmin kernel.  max_queries bounds the (possibly device-side)
+// query count and sizes the grid; surplus blocks exit before touching LDS.
+size_t table_lds_doubles(const svsdf_ctx *ctx) {
+  return 4 * (size_t)ctx->K + 4 * (size_t)((ctx->K + kChunk - 1) / kChunk);
 }
 
-template <int S, int G>
-void launch_refine_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries,
-                      const double *seed_t, const double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl,
-                      int work_idx) {
+template <int S, int G, int U>
+void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries, double *out_sdf,
+                     double *out_t, BatchCtl *ctl, int work_idx) {
+  const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
-  // small persistent blocks (fine-grained dynamic fetch), trajectory in LDS
   const int blk = ctx->block;
-  const size_t lds = (size_t)traj_lds_doubles(ctx->N) * sizeof(double);
+  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N)) * sizeof(double);
   const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  hipLaunchKernelGGL((k_refine<S, G>), dim3(grid), dim3(blk), lds, st, ctx->d_traj, ctx->sp, qs, seed_t, seed_min,
-                     out_sdf, out_t, ctl, work_idx);
+  hipLaunchKernelGGL((k_solve<S, G, U>), dim3(grid), dim3(blk), lds, st, ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks,
+                     ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -198,36 +189,36 @@ void launch_refine_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long l
   ctx->stats.solve_launches++;
 }
 
-#define SVSDF_FOR_G(G, CALL) \
-  switch (G) { case 1: CALL(1); break; case 2: CALL(2); break; case 8: CALL(8); break; default: CALL(4); break; }
-
 template <int S>
-void launch_seed_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, const SampleGen &sg, long long mq,
-                   double *seed_t, double *seed_min, BatchCtl *ctl, int work_idx) {
-  switch (G) {
-    case 1: launch_seed_sg<S, 1>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
-    case 4: launch_seed_sg<S, 4>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
-    case 16: launch_seed_sg<S, 16>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
-    default: launch_seed_sg<S, 8>(ctx, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx); break;
+void launch_solve_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, double *out_sdf,
+                    double *out_t, BatchCtl *ctl, int work_idx) {
+  // G lanes per query, U interleaved evaluations per lane (G * U candidates / samples per step)
+  switch (G * 10 + ctx->U) {
+    case 11: launch_solve_sg<S, 1, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+    case 21: launch_solve_sg<S, 2, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+    case 22: launch_solve_sg<S, 2, 2>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+    case 42: launch_solve_sg<S, 4, 2>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+    case 81: launch_solve_sg<S, 8, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+    case 82: launch_solve_sg<S, 8, 2>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+    default: launch_solve_sg<S, 4, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
   }
 }
-template <int S>
-void launch_refine_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, const double *seed_t,
-                     const double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl, int work_idx) {
-#define CALLG(GG) launch_refine_sg<S, GG>(ctx, st, qs, mq, seed_t, seed_min, out_sdf, out_t, ctl, work_idx)
-  SVSDF_FOR_G(G, CALLG)
-#undef CALLG
-}
 
-void launch_seed(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, const SampleGen &sg, long long mq,
-                 double *seed_t, double *seed_min, BatchCtl *ctl, int work_idx) {
-#define CALL(S) launch_seed_s<S>(ctx, G, st, qs, sg, mq, seed_t, seed_min, ctl, work_idx)
+void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, double *out_sdf,
+                  double *out_t, BatchCtl *ctl, int work_idx) {
+#define CALL(S) launch_solve_s<S>(ctx, G, st, qs, mq, out_sdf, out_t, ctl, work_idx)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
 }
-void launch_refine(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, const double *seed_t,
-                   const double *seed_min, double *out_sdf, double *out_t, BatchCtl *ctl, int work_idx) {
-#define CALL(S) launch_refine_s<S>(ctx, G, st, qs, mq, seed_t, seed_min, out_sdf, out_t, ctl, work_idx)
+
+void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
+  const long long pts = std::max(1, ctx->bcount[b]);
+  const unsigned grid = (unsigned)std::min<long long>((pts * 32 + kRoundBlock - 1) / kRoundBlock, 1024);
+  const size_t lds = table_lds_doubles(ctx) * sizeof(double);
+#define CALL(S)                                                                                          \
+  hipLaunchKernelGGL((k_round<S>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,      \
+                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, ctx->select_delta, \
+                     ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
 }
@@ -238,7 +229,7 @@ void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
 #define CALL(S)                                                                                      \
   hipLaunchKernelGGL((k_classify<S>), dim3(grid), dim3(kBlock), lds, st, ctx->d_traj, ctx->sp,       \
                      ctx->d_px, ctx->d_py, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,       \
-                     ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->P, ctx->d_ctl + b)
+                     ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->d_ctl + b)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
 }
@@ -303,36 +294,20 @@ int join_batches(svsdf_ctx *ctx) {
   return SVSDF_OK;
 }
 
-// GSIP iterations [it0, it1) for every batch: seed the freshly emitted circle samples, select
-// the samples worth solving (upper-bound selection), solve them, close / extend the rounds.
-void enqueue_iterations(svsdf_ctx *ctx, int it0, int it1) {
-  for (int it = it0; it < it1; ++it) {
-    for (int b = 0; b < ctx->nbatch; ++b) {
-      hipStream_t st = ctx->bstream[b];
-      BatchCtl *ctl = ctx->d_ctl + b;
-      const long long cap = (long long)ctx->bcount[b] * kMaxSlots;
-      const size_t off = (size_t)ctx->bstart[b] * kMaxSlots;
-      const int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
-      QuerySet qseed{};
-      qseed.qx = ctx->gs.sqx; qseed.qy = ctx->gs.sqy; qseed.count_ptr = &ctl->n_seed[it];
-      qseed.slots = ctx->gs.seedl[it & 1] + off; qseed.n_outer = 1;
-      SampleGen sg{};
-      sg.cx = ctx->d_px; sg.cy = ctx->d_py; sg.pt = ctx->gs.pt; sg.r = ctx->gs.r; sg.theta0 = ctx->gs.theta0;
-      sg.theta_res = ctx->gs.theta_res; sg.sqx = ctx->gs.sqx; sg.sqy = ctx->gs.sqy; sg.sqth = ctx->gs.sqth;
-      sg.sq_sdf = ctx->gs.sq_sdf; sg.stride = ctx->P;
-      launch_seed(ctx, ctx->G_seed, st, qseed, sg, cap, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctl, 2 * (it + 1));
-      const unsigned grid = (unsigned)std::min<long long>(((long long)ctx->bcount[b] + kBlock - 1) / kBlock, 1024);
-      hipLaunchKernelGGL(k_select, dim3(grid), dim3(kBlock), 0, st, ctx->gs, ctx->d_sq_seed_min, ctx->P, it,
-                         ctx->select_delta, ctl);
-      QuerySet qsol = qseed;
-      qsol.count_ptr = &ctl->n_solve[it];
-      qsol.slots = ctx->gs.solve[it & 1] + off;
-      launch_refine(ctx, G, st, qsol, cap, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl,
-                    2 * (it + 1) + 1);
-      hipLaunchKernelGGL(k_gsip, dim3(grid), dim3(kBlock), 0, st, ctx->d_px, ctx->d_py, ctx->gs,
-                         ctx->d_sq_seed_min, ctx->P, it, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx,
-                         ctx->d_res_gy, ctl);
-    }
+// GSIP pipeline per batch:  R0 S0 R1 S1 ... S(k-1) Rk   with
+//   R_i = k_round(i): close the rounds whose samples S_(i-1) solved, open the next ones, select
+//   S_i = k_solve over the samples R_i selected.
+// enqueue_solve_round(i) enqueues S_i then R_(i+1).
+void enqueue_solve_round(svsdf_ctx *ctx, int it) {
+  for (int b = 0; b < ctx->nbatch; ++b) {
+    hipStream_t st = ctx->bstream[b];
+    BatchCtl *ctl = ctx->d_ctl + b;
+    QuerySet q{};
+    q.qx = ctx->gs.sqx; q.qy = ctx->gs.sqy; q.count_ptr = &ctl->n_solve[it];
+    q.slots = ctx->gs.solve + (size_t)ctx->bstart[b] * kMaxSlots; q.n_outer = 1;
+    const int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
+    launch_solve(ctx, G, st, q, (long long)ctx->bcount[b] * kMaxSlots, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl, it + 1);
+    launch_round(ctx, st, b, it + 1);
   }
 }
 
@@ -352,7 +327,6 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), ctx->stream));
   HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
-  // enqueue round-robin over the batches so that every stream has work early
   for (int b = 0; b < ctx->nbatch; ++b) {
     hipStream_t st = ctx->bstream[b];
     BatchCtl *ctl = ctx->d_ctl + b;
@@ -360,11 +334,11 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     QuerySet qm{};
     qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
     qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
-    launch_seed(ctx, ctx->G_seed, st, qm, SampleGen{}, ctx->bcount[b], ctx->d_seed_t, ctx->d_seed_min, ctl, 0);
-    launch_refine(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctl, 1);
+    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0);
     launch_classify(ctx, st, b);
+    launch_round(ctx, st, b, 0);
   }
-  enqueue_iterations(ctx, 0, ctx->first_iters);
+  for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
   ctx->it_done = ctx->first_iters;
   return join_batches(ctx);
 }
@@ -390,11 +364,11 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, kOutPartial * sizeof(double), ctx->stream));
   }
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
-                     ctx->nbatch, ctx->it_done, reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
+                     ctx->nbatch, ctx->it_done, ctx->d_nonfinite,
+                     reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
   ctx->e_end = next_event(ctx);
   (void)hipEventRecord(ctx->ev_pool[ctx->e_end], ctx->stream);
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&ctx->h_nonfinite, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return SVSDF_OK;
@@ -406,9 +380,9 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   int rc = reduce_and_read(ctx, with_partial);
   if (rc) return rc;
   const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out + kOutPartial);
-  while (st[5] > 0 && ctx->it_done < kMaxIter) {
-    const int it1 = std::min(ctx->it_done + 4, (int)kMaxIter);
-    enqueue_iterations(ctx, ctx->it_done, it1);
+  while (st[5] > 0 && ctx->it_done < kMaxIter) {  // solves requested by the last k_round are pending
+    const int it1 = std::min(ctx->it_done + 3, (int)kMaxIter);
+    for (int it = ctx->it_done; it < it1; ++it) enqueue_solve_round(ctx, it);
     ctx->it_done = it1;
     if ((rc = join_batches(ctx))) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), ctx->stream));
@@ -435,7 +409,20 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
     }
     ctx->stats.solve_ms = sum;
   }
-  if (ctx->h_nonfinite || st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
+#ifdef SVSDF_TIMING
+  if (std::getenv("SVSDF_DUMP_TIMING")) {
+    std::vector<unsigned long long> tm(8 * (kMaxIter + 4));
+    (void)hipMemcpy(tm.data(), reinterpret_cast<char *>(ctx->d_ctl) + kMaxBatches * sizeof(BatchCtl), tm.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMemset(reinterpret_cast<char *>(ctx->d_ctl) + kMaxBatches * sizeof(BatchCtl), 0, tm.size() * 8);
+    for (int w = 0; w < kMaxIter + 2; ++w) {
+      const unsigned long long *t = &tm[8 * w];
+      if (!t[5]) continue;
+      std::fprintf(stderr, "[timing] launch %2d: waves %6llu  avg us/wave: scan %7.1f layers %7.1f gd %7.1f life %7.1f  max life %7.1f  gd steps/wave %6.1f\n",
+                   w, t[5], t[0] / 100.0 / t[5], t[1] / 100.0 / t[5], t[2] / 100.0 / t[5], t[3] / 100.0 / t[5], t[6] / 100.0, (double)t[4] / t[5]);
+    }
+  }
+#endif
+  if (st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
 }
 
@@ -456,8 +443,6 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   int rc = 0;
   if ((rc = dev_alloc(ctx, &ctx->d_px, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_py, P))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_seed_t, P))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_seed_min, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_sdf, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_t, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_res_sdf, P))) return rc;
@@ -470,21 +455,17 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.theta_res, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.iter, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.nsamp, P))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->gs.supp, P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.phase, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[0], P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[1], P))) return rc;
-  for (int k = 0; k < 2; ++k) {
-    if ((rc = dev_alloc(ctx, &ctx->gs.solve[k], P * kMaxSlots))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->gs.seedl[k], P * kMaxSlots))) return rc;
-  }
   const size_t S = P * kMaxSlots;
+  if ((rc = dev_alloc(ctx, &ctx->gs.solve, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqx, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqy, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqth, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sq_ub, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_sdf, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_t, S))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_sq_seed_t, S))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_sq_seed_min, S))) return rc;
   return SVSDF_OK;
 }
 
@@ -635,6 +616,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     default: sp.c0x = 0.0; sp.c0y = 0.0; break;
   }
   sp.r_bound = 0.0;
+  sp.identity = (sp.tx == 0.0 && sp.ty == 0.0 && sp.r00 == 1.0 && sp.r01 == 0.0 && sp.r10 == 0.0 && sp.r11 == 1.0) ? 1 : 0;
   sp.nverts = 0;
   sp.verts = nullptr;
   if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
@@ -658,7 +640,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
-  if (const char *e = std::getenv("SVSDF_G_SEED")) { const int g = std::atoi(e); if (g == 1 || g == 4 || g == 8 || g == 16) ctx->G_seed = g; }
+  if (const char *e = std::getenv("SVSDF_U")) ctx->U = std::atoi(e) == 2 ? 2 : 1;
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) ctx->select_delta = std::atof(e);
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
@@ -670,13 +652,13 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   }
   if (hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess) return bail("event creation failed");
   if (hipMalloc((void **)&ctx->d_traj, sizeof(TrajDev)) != hipSuccess ||
-      hipMalloc((void **)&ctx->d_ctl, kMaxBatches * sizeof(BatchCtl)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_ctl, kMaxBatches * sizeof(BatchCtl) + 8 * 8 * (kMaxIter + 4)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_nonfinite, sizeof(int)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_sums, kOutPartial * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_out, kOutDoubles * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_out, kOutDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
     return bail("device allocation failed");
-  if (hipMemset(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl)) != hipSuccess) return bail("hipMemset failed");
+  if (hipMemset(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl) + 8 * 8 * (kMaxIter + 4)) != hipSuccess) return bail("hipMemset failed");
   {  // shape bound radius R: sdf_shape(q) >= |q| - R, sampled on a polar grid + safety margin
     if (hipMemset(ctx->d_out, 0, sizeof(double)) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;
@@ -700,11 +682,11 @@ void svsdf_destroy(svsdf_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {ctx->d_poly, ctx->d_px, ctx->d_py, ctx->d_traj, ctx->d_in, ctx->d_pose, ctx->d_chunks,
-                  ctx->d_seed_t, ctx->d_seed_min, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,
-                  ctx->d_res_gx, ctx->d_res_gy, ctx->d_sq_seed_t, ctx->d_sq_seed_min, ctx->gs.pt, ctx->gs.r,
-                  ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.list[0],
-                  ctx->gs.list[1], ctx->gs.supp, ctx->gs.solve[0], ctx->gs.solve[1], ctx->gs.seedl[0], ctx->gs.seedl[1], ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth, ctx->gs.sq_sdf, ctx->gs.sq_t,
-                  ctx->d_ctl, ctx->d_block_partials, ctx->d_sums, ctx->d_out, ctx->d_nonfinite};
+                  ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs.pt,
+                  ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.phase,
+                  ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
+                  ctx->gs.sq_ub, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl, ctx->d_block_partials, ctx->d_sums,
+                  ctx->d_out, ctx->d_nonfinite};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_in) (void)hipHostFree(ctx->h_in);

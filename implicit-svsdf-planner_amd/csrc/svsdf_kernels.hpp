@@ -7,10 +7,13 @@
 // Pipeline per evaluation (all FP64; see DESIGN.md "Kernels"):
 //   k_prep      trajectory -> per-piece monomials, cumulative start times, layer-1 pose table,
 //               chunk bounding circles for the exact scan pruning
-//   k_seed      choiceTInit layer 1 (SWM:538-581) over the shared pose table
-//   k_refine    choiceTInit layers 2-4 + gradientDescent (SWM:1249-1325)
-//   k_classify  exterior: FD gradient; interior: GSIP state + first circle samples
-//   k_gsip      per GSIP round: max over samples, radius update, termination / next samples
+//   k_solve     one argmin-over-t solve per query: choiceTInit (SWM:538-581, layer 1 over the
+//               shared pose table with exact chunk pruning, layers 2-4) + gradientDescent
+//               (SWM:1249-1325); G lanes cooperate on one query
+//   k_classify  exterior: FD gradient; interior: GSIP state
+//   k_round     32 lanes per interior point: close the previous GSIP round (max over the solved
+//               samples, radius update, termination) and open the next one (circle samples, cheap
+//               upper bounds, selection of the samples worth solving)
 //   k_assemble  per-point cost/gradient contribution (BEO:786-865) + block-level reduction
 //   k_final     fixed-order sum of block partials, suffix sum for the duration gradient
 // The query points are split into batches that run the whole chain on their own HIP stream
@@ -32,7 +35,7 @@ constexpr int kMaxBatches = 8;
 // GSIP iterations: a round normally takes one iteration, plus one supplementary iteration when
 // the upper-bound selection (k_select / k_gsip) has to solve more samples of the same round.
 constexpr int kMaxIter = 24;
-constexpr int kWorkCounters = 2 * (kMaxIter + 1);  // one per (seed|refine) launch of a batch
+constexpr int kWorkCounters = kMaxIter + 2;        // one per k_solve launch of a batch
 constexpr double kUnsolved = -1e300;               // sq_sdf marker: sample not (yet) solved
 
 // Trajectory as the device sees it (global memory; staged into LDS by each block).
@@ -59,7 +62,7 @@ struct BatchCtl {
   int start, count;               // points [start, start + count) of the sorted shard
   int n_active[kMaxIter + 2];     // [i] = GSIP points entering iteration i; [0] = interior points
   int n_solve[kMaxIter + 2];      // [i] = sample solves requested for iteration i
-  int n_seed[kMaxIter + 2];       // [i] = new samples to seed in iteration i
+  int n_seed[kMaxIter + 2];       // [i] = circle samples emitted in iteration i (statistics)
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
   int pad;
@@ -123,6 +126,31 @@ __device__ __forceinline__ void piece_vel(const double *__restrict__ c, double s
   }
 }
 
+// per-lane cache of the current piece and its [S_lo, S_hi] interval (avoids the LDS walk when
+// consecutive evaluations stay in one piece, which is the rule in the scan layers and the descent)
+struct PieceCache {
+  int piece;
+  double lo, hi;
+};
+__device__ __forceinline__ PieceCache piece_cache_init() { PieceCache pc; pc.piece = 0; pc.lo = 1.0; pc.hi = 0.0; return pc; }
+
+__device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, PieceCache &pc) {
+  // same piece as locate_piece: t in (S[i], S[i+1]] (t <= S[1] for i = 0, t > S[N-1] for i = N-1)
+  if (!(t > pc.lo && t <= pc.hi)) {
+    pc.piece = locate_piece(tr, t, pc.piece);
+    pc.lo = (pc.piece == 0) ? -1e300 : tr.S[pc.piece];
+    pc.hi = (pc.piece == tr.N - 1) ? 1e300 : tr.S[pc.piece + 1];
+  }
+  const int piece = pc.piece;
+  const double s = t - ((piece == 0) ? 0.0 : pc.lo);
+  double x, y, yaw;
+  piece_pos(tr.c + piece * 18, s, x, y, yaw);
+  Pose p;
+  p.x = x; p.y = y;
+  sincos(yaw, &p.sn, &p.cs);
+  return p;
+}
+
 __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, int &piece) {
   piece = locate_piece(tr, t, piece);
   const double s = t - tr.S[piece];
@@ -149,6 +177,12 @@ template <int SHAPE>
 __device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp, double px,
                                          double py, double t, int &piece) {
   const Pose p = pose_at(tr, t, piece);
+  return sdf_from_pose<SHAPE>(sp, p, px, py);
+}
+template <int SHAPE>
+__device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp, double px,
+                                         double py, double t, PieceCache &pc) {
+  const Pose p = pose_at(tr, t, pc);
   return sdf_from_pose<SHAPE>(sp, p, px, py);
 }
 
@@ -241,18 +275,6 @@ struct QuerySet {
   int base;
   int n_outer;
   const int *slots;       // explicit slot list (n = *count_ptr entries, overrides the rest) or null
-  const int *skip;        // per-entry skip flags indexed by base + a (may be null)
-};
-
-// GSIP circle samples are materialised by the seed kernel itself (one lane group per sample):
-// sample j of interior point ia sits at centre + r (cos th_j, sin th_j), th_j = th0 + j*th_res
-// by repeated addition (SampleSet2D::getElements / getElementPos, SWM:36-39, 60-71).
-struct SampleGen {
-  const double *cx, *cy;      // main points
-  const int *pt;              // interior -> main point index
-  const double *r, *theta0, *theta_res;
-  double *sqx, *sqy, *sqth, *sq_sdf;
-  size_t stride;
 };
 
 __device__ __forceinline__ long long qs_total(const QuerySet &qs, int &n) {
@@ -265,7 +287,7 @@ __device__ __forceinline__ bool qs_slot(const QuerySet &qs, int n, long long q, 
   const int e = (int)(q % n), j = (int)(q / n);
   const int a = qs.list ? qs.list[e] : e;
   slot = (size_t)j * qs.stride + (size_t)qs.base + (size_t)a;
-  return !(qs.skip && qs.skip[qs.base + a]);
+  return true;
 }
 
 // G lanes cooperate on one query (64/G queries per wave).
@@ -310,77 +332,66 @@ __device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wav
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_seed: choiceTInit layer 1 (SWM:549-576, first pass of the while loop) over the shared pose
-// table.  Poses at the scan times do not depend on the query point, so they are computed once
-// (k_prep) and every query only does the rigid transform + shape SDF per sample.  Chunks of 8
-// samples whose lower bound exceeds the running minimum are skipped: exact, because a skipped
-// sample can never be (or tie with) the minimum the reference's strict `<` scan keeps.
+// k_solve: getSDFofSweptVolume<false,true> (SWM:844-866) without its FD gradient, for the main
+// points of a batch or for the selected GSIP circle samples.
+//  * choiceTInit layer 1 (SWM:549-576, first pass): poses at the scan times do not depend on the
+//    query point, so they come from the table k_prep built (LDS) and a query only does the rigid
+//    transform + shape SDF per sample.  Chunks of 8 samples whose lower bound exceeds the running
+//    minimum are skipped: exact, a skipped sample can never be (or tie with) the minimum the
+//    reference's strict `<` scan keeps.
+//  * layers 2-4 (SWM:557-577) and gradientDescent (SWM:1249-1325): the 21 samples of a layer and
+//    the <= 29 candidates of a halving ladder are evaluated G at a time.  A ladder's candidates do
+//    not depend on each other, so the first accepted one is exactly the one the sequential loop
+//    accepts (bit-identical result, shorter dependent chain).  getSDF_DOT (SWM:799-806) is
+//    evaluated once per descent pass: x does not change inside the ladder, so the reference's
+//    per-trial re-evaluation returns the same number.
+// LDS: [pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
 // ---------------------------------------------------------------------------------------------
-template <int SHAPE, int G>
+template <int SHAPE, int G, int U>
 __global__ void __launch_bounds__(kBlock)
-k_seed(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
-       const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, SampleGen sg,
-       double *__restrict__ seed_t, double *__restrict__ seed_min, int prune,
-       BatchCtl *__restrict__ ctl, int work_idx) {
-  extern __shared__ double seed_lds[];
+k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
+        const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
+        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx) {
+  extern __shared__ double solve_lds[];
   int n;
   const long long total = qs_total(qs, n);
   if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
-  Pose *pose = reinterpret_cast<Pose *>(seed_lds);
-  Chunk *chunks = reinterpret_cast<Chunk *>(seed_lds + 4 * (size_t)K);
+  Pose *pose = reinterpret_cast<Pose *>(solve_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(solve_lds + 4 * (size_t)K);
   {
     const double *src = reinterpret_cast<const double *>(pose_g);
-    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) seed_lds[i] = src[i];
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) solve_lds[i] = src[i];
     const double *srcc = reinterpret_cast<const double *>(chunks_g);
-    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) seed_lds[4 * (size_t)K + i] = srcc[i];
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) solve_lds[4 * (size_t)K + i] = srcc[i];
   }
-  __syncthreads();
+  const TrajL tr = stage_traj(trg, solve_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
   const int li = Grp<G>::li();
-  unsigned n_scan = 0;
-  long long gq_first = 0;
-  // the scan of one query is short: take up to 8 wave-loads per atomic, fewer when the launch
-  // has little work per resident wave (keeps every wave busy instead of a few waves for long)
-  const long long per_wave = total / ((long long)gridDim.x * (blockDim.x / 64) * (64 / G));
-  const int nfetch = (int)(per_wave < 1 ? 1 : (per_wave > 8 ? 8 : per_wave));
-  for (int guard = 0; guard < (1 << 24); ++guard) {
-    long long wave_base = 0;
-    {
-      unsigned base = 0;
-      if ((threadIdx.x & 63) == 0) base = atomicAdd(&ctl->work[work_idx], (unsigned)(nfetch * 64 / G));
-      base = __builtin_amdgcn_readfirstlane(base);
-      wave_base = (long long)base;
-      gq_first = wave_base + (long long)((threadIdx.x & 63) / G);
-    }
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  unsigned n_eval = 0, n_scan = 0, n_solved = 0;
+#ifdef SVSDF_TIMING
+  long long tm_scan = 0, tm_lay = 0, tm_gd = 0, tm_steps = 0, tm_start = wall_clock64();
+#endif
+  for (int guard = 0; guard < (1 << 26); ++guard) {
+    long long wave_base;
+    const long long gq = fetch_work<G>(&ctl->work[work_idx], wave_base);
     if (wave_base >= total) break;
-    for (int sub = 0; sub < nfetch; ++sub) {
-    const long long gq = gq_first + (long long)sub * (64 / G);
+#ifdef SVSDF_TIMING
+    const long long tq0 = wall_clock64();
+#endif
     double px = 0.0, py = 0.0;
     size_t slot = 0;
     bool live = gq < total;
     if (live) live = qs_slot(qs, n, gq, slot);
     if (live) {
-      if (sg.sqx) {  // materialise the circle sample (slot = j * stride + ia)
-        const int j = (int)(slot / sg.stride);
-        const size_t ia = slot - (size_t)j * sg.stride;
-        double theta = sg.theta0[ia];
-        const double theta_res = sg.theta_res[ia];
-        for (int q = 0; q < j; ++q) theta += theta_res;
-        const double r = sg.r[ia];
-        const int i = sg.pt[ia];
-        px = sg.cx[i] + 1.0 * r * cos(theta);
-        py = sg.cy[i] + 1.0 * r * sin(theta);
-        if (li == 0) { sg.sqx[slot] = px; sg.sqy[slot] = py; sg.sqth[slot] = theta; sg.sq_sdf[slot] = kUnsolved; }
-      } else {
-        px = qs.qx[slot]; py = qs.qy[slot];
-        live = (px == px);  // NaN marks an unused slot (whole group)
-      }
+      px = qs.qx[slot]; py = qs.qy[slot];
+      live = (px == px);  // NaN marks an unused slot (whole group)
     }
     if (live) {
+    // ---- choiceTInit layer 1 over the pose table
     double best_d = 1e9;   // min_dis initial value (SWM:545)
     int best_k = 0x7fffffff;
-
     auto eval_chunk = [&](int c) {
       double d_loc = 1e300;
       int k_loc = 0x7fffffff;
@@ -398,7 +409,6 @@ k_seed(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
       Grp<G>::min_dk(d_loc, k_loc);
       if (d_loc < best_d || (d_loc == best_d && k_loc < best_k)) { best_d = d_loc; best_k = k_loc; }
     };
-
     if (!prune) {
       for (int c = 0; c < nch; ++c) eval_chunk(c);
     } else {
@@ -430,82 +440,61 @@ k_seed(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
         c = c + first + 1;
       }
     }
-    if (li == 0) {
-      seed_t[slot] = tk[best_k];
-      seed_min[slot] = best_d;
-    }
-    }  // live
-    }  // sub
-  }
-  unsigned long long tot = n_scan;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
-  if ((threadIdx.x & 63) == 0 && tot) { atomicAdd(&ctl->stat_scan, tot); atomicAdd(&ctl->stat_evals, tot); }
-}
+    PieceCache piece = piece_cache_init();
+    double time_seed = tk[best_k];
+    double min_dis = best_d;
+#ifdef SVSDF_TIMING
+    const long long tq1 = wall_clock64();
+#endif
 
-// ---------------------------------------------------------------------------------------------
-// k_refine: choiceTInit layers 2-4 (SWM:557-577) + gradientDescent (SWM:1249-1325) from the
-// layer-1 seed.  The 21 samples of a layer and the <= 29 candidates of a halving ladder are
-// evaluated G at a time: a ladder's candidates do not depend on each other, so the first
-// accepted one is exactly the one the sequential reference loop accepts (bit-identical result,
-// shorter dependent chain).  getSDF_DOT (SWM:799-806) is evaluated once per descent pass: x does
-// not change inside the ladder, so the reference's per-trial re-evaluation returns the same number.
-// ---------------------------------------------------------------------------------------------
-template <int SHAPE, int G>
-__global__ void __launch_bounds__(kBlock)
-k_refine(const TrajDev *__restrict__ trg, ShapeParams sp, QuerySet qs,
-         const double *__restrict__ seed_t, const double *__restrict__ seed_min,
-         double *__restrict__ out_sdf, double *__restrict__ out_t, BatchCtl *__restrict__ ctl,
-         int work_idx) {
-  extern __shared__ double refine_lds[];
-  int n;
-  const long long total = qs_total(qs, n);
-  if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
-  const TrajL tr = stage_traj(trg, refine_lds);
-  const int li = Grp<G>::li();
-  const double inf = __longlong_as_double(0x7ff0000000000000ll);
-  unsigned n_eval = 0, n_solved = 0;
-  for (int guard = 0; guard < (1 << 26); ++guard) {
-    long long wave_base;
-    const long long gq = fetch_work<G>(&ctl->work[work_idx], wave_base);
-    if (wave_base >= total) break;
-    double px = 0.0, py = 0.0;
-    size_t slot = 0;
-    bool live = gq < total;
-    if (live) live = qs_slot(qs, n, gq, slot);
-    if (live) {
-      px = qs.qx[slot]; py = qs.qy[slot];
-      live = (px == px);
-    }
-    if (live) {
-    int piece = 0;
-    double time_seed = seed_t[slot];
-    double min_dis = seed_min[slot];
-
-    // ---- choiceTInit layers 2-4
+    // ---- choiceTInit layers 2-4: W = G*U samples per step, lane li takes li, li+G, ...
+    constexpr int W = G * U;
     double dt = 0.15;
     dt *= 0.1;
     for (int layer = 2; layer <= 4; ++layer) {
       const double t0 = dmax(0.0, time_seed - 10 * dt);
       const double loop_terminal = dmin(tr.dur, time_seed + 10 * dt);
-      double t = t0;  // lane li starts at the li-th accumulated sample
-      for (int i = 0; i < li; ++i) t += dt;
-      int kbase = 0;
-      while (Grp<G>::bcast(t, 0) <= loop_terminal) {
-        const bool valid = t <= loop_terminal;
-        double d = inf;
-        if (valid) { d = sdf_at<SHAPE>(tr, sp, px, py, t, piece); ++n_eval; }
-        int k = kbase + li;
-        Grp<G>::min_dk(d, k);
-        const double tb = Grp<G>::bcast(t, k - kbase);
-        if (d < min_dis) { time_seed = tb; min_dis = d; }
+      double t[U];
+      t[0] = t0;
+      for (int i = 0; i < li; ++i) t[0] += dt;   // the li-th accumulated sample
 #pragma unroll
-        for (int i = 0; i < G; ++i) t += dt;
-        kbase += G;
+      for (int u = 1; u < U; ++u) {
+        t[u] = t[u - 1];
+#pragma unroll
+        for (int i = 0; i < G; ++i) t[u] += dt;
+      }
+      int kbase = 0;
+      while (Grp<G>::bcast(t[0], 0) <= loop_terminal) {
+        double d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          d[u] = inf;
+          if (t[u] <= loop_terminal) { d[u] = sdf_at<SHAPE>(tr, sp, px, py, t[u], piece); ++n_eval; }
+        }
+        double db = d[0], tb = t[0];
+        int k = kbase + li;
+#pragma unroll
+        for (int u = 1; u < U; ++u)
+          if (d[u] < db) { db = d[u]; tb = t[u]; k = kbase + li + G * u; }  // strict: earliest kept
+        const int kmine = k;
+        Grp<G>::min_dk(db, k);
+        // broadcast the time of the winning sample from the lane that holds it
+        const int src = (k - kbase) % G;
+        const double tw = Grp<G>::bcast((k == kmine) ? tb : 0.0, src);
+        if (db < min_dis) { time_seed = tw; min_dis = db; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int i = 0; i < W; ++i) t[u] += dt;
+        }
+        kbase += W;
       }
       dt *= 0.1;
     }
 
+#ifdef SVSDF_TIMING
+    const long long tq2 = wall_clock64();
+#endif
     // ---- gradientDescent
     const double t_min = dmax(0.0, time_seed - 3.4);
     const double t_max = dmin(time_seed + 3.4, tr.dur);
@@ -538,25 +527,41 @@ k_refine(const TrajDev *__restrict__ trg, ShapeParams sp, QuerySet qs,
       const double sgn = (double)((int)(g > 0) - (int)(g < 0));
       prev_x = x;
       bool accepted = false;
-      for (int j0 = 1; j0 <= 29 && !accepted; j0 += G) {
-        const int j = j0 + li;  // div
-        const bool valid = j <= 29;
-        const double tau = ldexp(0.01, 1 - j);  // alpha halved (div - 1) times: exact
-        const double change = -tau * sgn;
-        double xc = x + change;
-        xc = dmax(dmin(xc, t_max), t_min);
-        double fc = inf;
-        if (valid) { fc = sdf_at<SHAPE>(tr, sp, px, py, xc, piece); ++n_eval; }
-        const unsigned m = Grp<G>::ballot(valid && ((fc - fx) < 0));
-        if (m != 0u) {
-          const int first = __ffs(m) - 1;
-          x = Grp<G>::bcast(xc, first);
-          fx = Grp<G>::bcast(fc, first);
-          iter += first + 1;
+      for (int j0 = 1; j0 <= 29 && !accepted; j0 += W) {
+#ifdef SVSDF_TIMING
+        ++tm_steps;
+#endif
+        double xc[U], fc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + li + G * u;  // div
+          const double tau = ldexp(0.01, 1 - j);  // alpha halved (div - 1) times: exact
+          const double change = -tau * sgn;
+          xc[u] = x + change;
+          xc[u] = dmax(dmin(xc[u], t_max), t_min);
+          fc[u] = inf;
+          if (j <= 29) { fc[u] = sdf_at<SHAPE>(tr, sp, px, py, xc[u], piece); ++n_eval; }
+        }
+        // first accepted div over the W candidates of this step
+        int jacc = 0x7fffffff;
+        double xa = 0.0, fa = 0.0;
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u)
+          if ((fc[u] - fx) < 0) { jacc = li + G * u; xa = xc[u]; fa = fc[u]; }
+        int jbest = jacc;
+        if constexpr (G > 1) {
+#pragma unroll
+          for (int m = G / 2; m >= 1; m >>= 1) jbest = min(jbest, __shfl_xor(jbest, m, G));
+        }
+        if (jbest != 0x7fffffff) {
+          const int src = jbest % G;
+          x = Grp<G>::bcast((jacc == jbest) ? xa : 0.0, src);
+          fx = Grp<G>::bcast((jacc == jbest) ? fa : 0.0, src);
+          iter += jbest + 1;
           accepted = true;
         } else {
           const int left = 29 - j0 + 1;
-          iter += (left < G) ? left : G;
+          iter += (left < W) ? left : W;
         }
       }
       if (!accepted) stop = true;
@@ -566,18 +571,36 @@ k_refine(const TrajDev *__restrict__ trg, ShapeParams sp, QuerySet qs,
       out_t[slot] = x;
       ++n_solved;
     }
+#ifdef SVSDF_TIMING
+    { const long long tq3 = wall_clock64(); tm_scan += tq1 - tq0; tm_lay += tq2 - tq1; tm_gd += tq3 - tq2; }
+#endif
     }  // live
   }
-  unsigned long long te = n_eval, ts = n_solved;
+#ifdef SVSDF_TIMING
+  if ((threadIdx.x & 63) == 0) {
+    // wall_clock64 ticks at 100 MHz; [scan, layers, gd, total wave life, gd steps, waves]
+    unsigned long long *tmo = reinterpret_cast<unsigned long long *>(ctl + kMaxBatches) + 8 * work_idx;
+    atomicAdd(&tmo[0], (unsigned long long)tm_scan); atomicAdd(&tmo[1], (unsigned long long)tm_lay);
+    atomicAdd(&tmo[2], (unsigned long long)tm_gd); atomicAdd(&tmo[3], (unsigned long long)(wall_clock64() - tm_start));
+    atomicAdd(&tmo[4], (unsigned long long)tm_steps); atomicAdd(&tmo[5], 1ull);
+    atomicMax(&tmo[6], (unsigned long long)(wall_clock64() - tm_start));
+  }
+#endif
+  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); }
-  if ((threadIdx.x & 63) == 0 && te) { atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); }
+  for (int m = 32; m >= 1; m >>= 1) {
+    te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && te) {
+    atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); atomicAdd(&ctl->stat_scan, tc);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // GSIP state (getTrueSDFofSweptVolume SWM:916-1018), one entry per interior point; every array
 // is indexed by (batch start + interior index within the batch).
 // ---------------------------------------------------------------------------------------------
+enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
 struct GsipState {
   int *pt;          // index of the (sorted) main point
   double *r;        // current circle radius
@@ -585,36 +608,22 @@ struct GsipState {
   double *theta_res;
   int *iter;        // 1..9
   int *nsamp;       // samples emitted for the current round
-  int *supp;        // 1: the point waits for supplementary sample solves of its current round
+  int *phase;       // kPhaseNew: a round has to be opened; kPhaseEval / kPhaseSupp: samples are out
   int *list[2];     // ping-pong compacted lists of still-active interior indices
-  int *solve[2];    // ping-pong lists of sample slots to solve (capacity kMaxSlots per point)
-  int *seedl[2];    // ping-pong lists of freshly emitted sample slots to seed
-  // sub-query slots [j * stride + batch start + a]
-  double *sqx, *sqy, *sqth, *sq_sdf, *sq_t;
+  int *solve;       // sample slots to solve in the current iteration (capacity kMaxSlots per point)
+  // sample slots [j * stride + batch start + a]
+  double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
 };
 
-// SampleSet2D::getElements + getElementPos (SWM:36-39, 60-71) for the single ring rk = 1.0.
-// Number of samples of a round (the theta loop of SampleSet2D::getElements, SWM:60-71) and their
-// slots pushed to the seed list; the seed kernel materialises the positions.
-__device__ __forceinline__ int emit_samples(size_t ia, size_t stride, double theta0, double theta_res,
-                                            int *__restrict__ seed_list, int *__restrict__ seed_count) {
-  int n = 0;
-  for (double theta = theta0; theta < theta0 + 2 * kPI; theta += theta_res) ++n;
-  n = n < kMaxSlots ? n : kMaxSlots;
-  int pos = atomicAdd(seed_count, n);
-  for (int j = 0; j < n; ++j) seed_list[pos++] = (int)((size_t)j * stride + ia);
-  return n;
-}
-
 // Per main point after the first solve: exterior -> FD gradient (getGradPrelAtTimeStamp,
-// SWM:779-788) and done; interior -> GSIP init (SWM:926-963).
+// SWM:779-788) and done; interior -> GSIP init (SWM:926-963), first round opened by k_round.
 template <int SHAPE>
 __global__ void __launch_bounds__(kBlock)
 k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__restrict__ px_,
            const double *__restrict__ py_, const double *__restrict__ sdf_,
            const double *__restrict__ t_, double *__restrict__ res_sdf,
            double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
-           GsipState gs, size_t stride, BatchCtl *__restrict__ ctl) {
+           GsipState gs, BatchCtl *__restrict__ ctl) {
   extern __shared__ double classify_lds[];
   const TrajL tr = stage_traj(trg, classify_lds);
   const int start = ctl->start, count = ctl->count;
@@ -657,120 +666,190 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
     // SampleSet2D::initSet (SWM:73-103)
     double theta0 = atan2(vx, -vy);
     if (theta0 < 0) theta0 += 2 * kPI;
-    const double theta_res = kPI + 0.1;
-    const double r0 = 10;
     gs.pt[ia] = i;
-    gs.r[ia] = r0;
+    gs.r[ia] = 10;               // r0 (SWM:927)
     gs.theta0[ia] = theta0;
-    gs.theta_res[ia] = theta_res;
+    gs.theta_res[ia] = kPI + 0.1;
     gs.iter[ia] = 1;
-    gs.supp[ia] = 0;
+    gs.nsamp[ia] = 0;
+    gs.phase[ia] = kPhaseNew;
     gs.list[0][ia] = a;
-    gs.nsamp[ia] = emit_samples(ia, stride, theta0, theta_res, gs.seedl[0] + (size_t)start * kMaxSlots,
-                                &ctl->n_seed[0]);
     res_t[i] = ts;  // real_t_star fallback
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Upper-bound selection of the GSIP samples (exact).  A round only uses the arg-max sample:
-// max_g, its t* and its angle (SWM:975-990).  Every sample's solved value is bounded above by
-// its layer-1 seed value U_j: layers 2-4 only lower min_dis, the descent starts at
-// f(time_seed) == min_dis and only accepts strict decreases.  So after solving a subset whose
-// best value is g*, any sample with U_j < g* can neither be nor tie with the maximum and need not
-// be solved.  k_select requests the samples within `delta` of the best bound; k_gsip requests the
-// rest of {U_j >= g*} (one supplementary iteration, rarely non-empty) before it closes the round.
+// k_round: 32 lanes per still-active interior point, lane j <-> circle sample j (<= 22 per round).
+//
+// Closing a round (SWM:965-1009; final assembly SWM:1011-1017): max_g, its t* and angle come
+// from the arg-max sample only.  Upper-bound selection (exact): every sample's solved value is
+// bounded above by ANY sdf value along its own scan -- layers 2-4 only lower min_dis, the descent
+// starts at f(time_seed) == min_dis and only accepts strict decreases -- so with ub_j = the
+// smallest of the 8 table-pose values of the chunk nearest to the sample, a sample with
+// ub_j < g* (g* = best solved value so far) can neither be nor tie with the round's maximum and
+// is never solved.  Opening a round requests the samples within `delta` of the best bound;
+// closing it first requests whatever of {ub_j >= g*} is still unsolved (supplementary iteration,
+// rarely non-empty).  The reference solves every sample; only the arg-max one is used.
+//
+// Opening a round: SampleSet2D::getElements / getElementPos (SWM:36-39, 60-71; one ring rk = 1)
+// with theta_j = theta0 + j * theta_res by repeated addition; expandSet(2, theta*) (SWM:105-110).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_select(GsipState gs, const double *__restrict__ seed_min, size_t stride, int it, double delta,
-         BatchCtl *__restrict__ ctl) {
+constexpr int kRoundBlock = 1024;  // 32 points per block: one set of list atomics per 32 points
+template <int SHAPE>
+__global__ void __launch_bounds__(kRoundBlock)
+k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
+        const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
+        const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta,
+        double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx,
+        double *__restrict__ res_gy, BatchCtl *__restrict__ ctl) {
+  extern __shared__ double round_lds[];
+  __shared__ int s_cnt[3][kRoundBlock / 32];   // per half-wave: solves, next-list entries, samples
+  __shared__ int s_base[2][kRoundBlock / 32];  // per half-wave: solve-list / next-list positions
   const int n_act = ctl->n_active[it];
-  const int start = ctl->start;
-  const int *cur = gs.list[it & 1] + start;
-  int *out = gs.solve[it & 1] + (size_t)start * kMaxSlots;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_act; e += gridDim.x * blockDim.x) {
-    const int a = cur[e];
-    const size_t ia = (size_t)start + a;
-    if (gs.supp[ia]) continue;  // its supplementary solves were requested by k_gsip
-    const int n = gs.nsamp[ia];
-    double umax = -1e300;
-    for (int j = 0; j < n; ++j) umax = fmax(umax, seed_min[(size_t)j * stride + ia]);
-    const double thr = umax - delta;
-    int cnt = 0;
-    for (int j = 0; j < n; ++j) cnt += (seed_min[(size_t)j * stride + ia] >= thr) ? 1 : 0;
-    int pos = atomicAdd(&ctl->n_solve[it], cnt);
-    for (int j = 0; j < n; ++j) {
-      const size_t sl = (size_t)j * stride + ia;
-      if (seed_min[sl] >= thr) out[pos++] = (int)sl;
-    }
+  const int ppb = blockDim.x / 32;  // points per block
+  if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
+  const int K = trg->K;
+  const int nch = (K + kChunk - 1) / kChunk;
+  Pose *pose = reinterpret_cast<Pose *>(round_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(round_lds + 4 * (size_t)K);
+  {
+    const double *src = reinterpret_cast<const double *>(pose_g);
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) round_lds[i] = src[i];
+    const double *srcc = reinterpret_cast<const double *>(chunks_g);
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) round_lds[4 * (size_t)K + i] = srcc[i];
   }
-}
-
-// One GSIP iteration per still-active interior point: close the round (SWM:965-1009, final
-// assembly SWM:1011-1017) or request supplementary solves.  Points that continue are appended to
-// the next iteration's compacted list.
-__global__ void __launch_bounds__(kBlock)
-k_gsip(const double *__restrict__ px_, const double *__restrict__ py_, GsipState gs,
-       const double *__restrict__ seed_min, size_t stride, int it, double *__restrict__ res_sdf,
-       double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
-       BatchCtl *__restrict__ ctl) {
-  const int n_act = ctl->n_active[it];
+  __syncthreads();
   const int start = ctl->start;
   const int *cur = gs.list[it & 1] + start;
   int *nxt = gs.list[(it + 1) & 1] + start;
-  int *solve_nxt = gs.solve[(it + 1) & 1] + (size_t)start * kMaxSlots;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_act; e += gridDim.x * blockDim.x) {
-    const int a = cur[e];
-    const size_t ia = (size_t)start + a;
-    const int i = gs.pt[ia];
-    const double cx = px_[i], cy = py_[i];
-    double max_g = -100000;
-    double real_t = res_t[i], star_th = 0.0;
-    const int n = gs.nsamp[ia];
-    for (int j = 0; j < n; ++j) {  // solved samples only; unsolved ones carry kUnsolved
-      const size_t s = (size_t)j * stride + ia;
-      const double cur_g = gs.sq_sdf[s];
-      if (cur_g > max_g) { max_g = cur_g; real_t = gs.sq_t[s]; star_th = gs.sqth[s]; }
-    }
-    // unsolved samples that could still reach max_g
-    int more = 0;
-    for (int j = 0; j < n; ++j) {
-      const size_t s = (size_t)j * stride + ia;
-      more += (gs.sq_sdf[s] == kUnsolved && seed_min[s] >= max_g) ? 1 : 0;
-    }
-    if (more > 0) {
-      int pos = atomicAdd(&ctl->n_solve[it + 1], more);
-      for (int j = 0; j < n; ++j) {
-        const size_t s = (size_t)j * stride + ia;
-        if (gs.sq_sdf[s] == kUnsolved && seed_min[s] >= max_g) solve_nxt[pos++] = (int)s;
+  int *solve = gs.solve + (size_t)start * kMaxSlots;
+  const int l = (int)(threadIdx.x & 31);
+  const int hw = (int)(threadIdx.x >> 5);
+  const unsigned lt_mask = (1u << l) - 1u;
+  auto ballot32 = [&](bool p) -> unsigned {
+    const unsigned long long m = __ballot(p);
+    return (unsigned)(((threadIdx.x & 32) ? (m >> 32) : m) & 0xffffffffull);
+  };
+  // block-uniform trip count; half-waves without a point still take part in the barriers
+  for (int e0 = (int)blockIdx.x * ppb; e0 < n_act; e0 += (int)gridDim.x * ppb) {
+    const int e = e0 + hw;
+    const bool active = e < n_act;
+    int a = 0, i = 0, n_emit = 0;
+    size_t ia = 0;
+    bool push_next = false, open = false, list_me = false;  // list_me: this lane adds its slot
+    unsigned mlist = 0u;                                     // lanes of the half-wave adding slots
+    double cx = 0.0, cy = 0.0, r = 0.0, theta0 = 0.0, theta_res = 0.0;
+    if (active) {
+      a = cur[e];
+      ia = (size_t)start + a;
+      i = gs.pt[ia];
+      cx = px_[i]; cy = py_[i];
+      r = gs.r[ia]; theta0 = gs.theta0[ia]; theta_res = gs.theta_res[ia];
+      open = gs.phase[ia] == kPhaseNew;
+      if (!open) {
+        // ---- close the round: max over the solved samples, first index wins ties (strict >)
+        const int n = gs.nsamp[ia];
+        const size_t s = (size_t)l * stride + ia;
+        const bool has = l < n;
+        const double g_l = has ? gs.sq_sdf[s] : kUnsolved;
+        double g = g_l;
+        int idx = l;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {
+          const double og = __shfl_xor(g, m, 32);
+          const int oi = __shfl_xor(idx, m, 32);
+          if (og > g || (og == g && oi < idx)) { g = og; idx = oi; }
+        }
+        double max_g = -100000, real_t = res_t[i], star_th = 0.0;
+        if (g > max_g) {
+          const size_t sb = (size_t)idx * stride + ia;
+          max_g = g; real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
+        }
+        // unsolved samples that could still reach max_g -> supplementary solves
+        const bool need = has && g_l == kUnsolved && gs.sq_ub[s] >= max_g;
+        const unsigned mneed = ballot32(need);
+        if (mneed != 0u) {
+          list_me = need; mlist = mneed; push_next = true;
+          if (l == 0) gs.phase[ia] = kPhaseSupp;
+        } else {
+          const double r_star = r - max_g;
+          const int iter = gs.iter[ia];
+          if (iter > 8 || fabs(max_g) < 0.1) {
+            if (l == 0) {
+              const double corx = cx + 1.0 * r_star * cos(star_th);
+              const double cory = cy + 1.0 * r_star * sin(star_th);
+              double gx = corx - cx, gy = cory - cy;
+              const double z = gx * gx + gy * gy;
+              if (z > 0.0) { const double nn = sqrt(z); gx = gx / nn; gy = gy / nn; }
+              res_sdf[i] = -r_star; res_t[i] = real_t; res_gx[i] = gx; res_gy[i] = gy;
+            }
+          } else {
+            // expandSet(2, theta*)
+            theta_res = theta_res / (2 + 1);
+            theta_res = dmax(0.3, theta_res);
+            r = r_star;
+            theta0 = star_th;
+            if (l == 0) {
+              gs.r[ia] = r; gs.theta_res[ia] = theta_res; gs.theta0[ia] = theta0; gs.iter[ia] = iter + 1;
+              res_t[i] = real_t;
+            }
+            open = true;
+          }
+        }
       }
-      gs.supp[ia] = 1;
-      nxt[atomicAdd(&ctl->n_active[it + 1], 1)] = a;
-      continue;
+      if (open) {
+        // ---- open a round: lane l <-> sample l
+        double theta = theta0;
+        for (int q = 0; q < l; ++q) theta += theta_res;
+        const bool valid = (theta < theta0 + 2 * kPI) && (l < kMaxSlots);
+        const unsigned mvalid = ballot32(valid);
+        n_emit = __popc(mvalid);  // theta increases with l: the valid lanes are a prefix
+        const size_t s = (size_t)l * stride + ia;
+        double ub = -1e300;
+        if (valid) {
+          const double qx = cx + 1.0 * r * cos(theta);
+          const double qy = cy + 1.0 * r * sin(theta);
+          // cheap upper bound: best table pose of the chunk whose bounding circle is nearest
+          double d2min = 1e300;  // any chunk gives a valid bound: take the nearest centre
+          int c0 = 0;
+          for (int c = 0; c < nch; ++c) {
+            const Chunk ch = chunks[c];
+            const double ex = qx - ch.cx, ey = qy - ch.cy;
+            const double d2 = ex * ex + ey * ey;
+            if (d2 < d2min) { d2min = d2; c0 = c; }
+          }
+          ub = 1e300;
+          const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
+          for (int k = c0 * kChunk; k < k1; ++k) ub = dmin(ub, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
+          gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_ub[s] = ub; gs.sq_sdf[s] = kUnsolved;
+        }
+        double umax = ub;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) umax = fmax(umax, __shfl_xor(umax, m, 32));
+        list_me = valid && ub >= umax - delta;
+        mlist = ballot32(list_me);
+        push_next = true;
+        if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = kPhaseEval; }
+      }
     }
-    gs.supp[ia] = 0;
-    const double r_star = gs.r[ia] - max_g;
-    const int iter = gs.iter[ia];
-    if (iter > 8 || fabs(max_g) < 0.1) {
-      const double corx = cx + 1.0 * r_star * cos(star_th);
-      const double cory = cy + 1.0 * r_star * sin(star_th);
-      double gx = corx - cx, gy = cory - cy;
-      const double z = gx * gx + gy * gy;
-      if (z > 0.0) { const double nn = sqrt(z); gx = gx / nn; gy = gy / nn; }
-      res_sdf[i] = -r_star; res_t[i] = real_t; res_gx[i] = gx; res_gy[i] = gy;
-      continue;
+    // ---- one set of list atomics per block iteration
+    if (l == 0) { s_cnt[0][hw] = __popc(mlist); s_cnt[1][hw] = push_next ? 1 : 0; s_cnt[2][hw] = n_emit; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t0 = 0, t1 = 0, t2 = 0;
+      for (int h = 0; h < ppb; ++h) {
+        s_base[0][h] = t0; s_base[1][h] = t1;
+        t0 += s_cnt[0][h]; t1 += s_cnt[1][h]; t2 += s_cnt[2][h];
+      }
+      const int b0 = t0 ? atomicAdd(&ctl->n_solve[it], t0) : 0;
+      const int b1 = t1 ? atomicAdd(&ctl->n_active[it + 1], t1) : 0;
+      if (t2) atomicAdd(&ctl->n_seed[it], t2);
+      for (int h = 0; h < ppb; ++h) { s_base[0][h] += b0; s_base[1][h] += b1; }
     }
-    // expandSet(2, theta*) (SWM:105-110)
-    double theta_res = gs.theta_res[ia] / (2 + 1);
-    theta_res = dmax(0.3, theta_res);
-    gs.r[ia] = r_star;
-    gs.theta_res[ia] = theta_res;
-    gs.theta0[ia] = star_th;
-    gs.iter[ia] = iter + 1;
-    res_t[i] = real_t;
-    gs.nsamp[ia] = emit_samples(ia, stride, star_th, theta_res, gs.seedl[(it + 1) & 1] + (size_t)start * kMaxSlots,
-                                &ctl->n_seed[it + 1]);
-    nxt[atomicAdd(&ctl->n_active[it + 1], 1)] = a;
+    __syncthreads();
+    if (list_me) solve[s_base[0][hw] + __popc(mlist & lt_mask)] = (int)((size_t)l * stride + ia);
+    if (push_next && l == 0) nxt[s_base[1][hw]] = a;
+    __syncthreads();
   }
 }
 
@@ -879,19 +958,19 @@ k_final(const double *__restrict__ block_partials, int nblocks, double *__restri
 // also gathers the per-batch counters.
 __global__ void k_finish(const double *__restrict__ sums, int N, double *__restrict__ partial,
                          const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
-                         unsigned long long *__restrict__ stats_out) {
+                         const int *__restrict__ nonfinite, unsigned long long *__restrict__ stats_out) {
   for (int k = threadIdx.x; k <= 18 * N; k += blockDim.x) partial[k] = sums[k];
   if (threadIdx.x == 0) {
     double suf = 0.0;
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
-    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = 0, rem = 0, seeded = 0, iters = 0;
+    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0;
     for (int b = 0; b < nbatch; ++b) {
       so += ctl[b].stat_solves; ev += ctl[b].stat_evals; sc += ctl[b].stat_scan;
       in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
-      rem += (unsigned long long)ctl[b].n_active[it_end];   // > 0: more iterations are needed
+      rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
       for (int i = 0; i <= it_end; ++i) {
         seeded += (unsigned long long)ctl[b].n_seed[i];
-        if (ctl[b].n_active[i] > 0 && (unsigned long long)(i + 1) > iters) iters = (unsigned long long)(i + 1);
+        if (ctl[b].n_solve[i] > 0 && (unsigned long long)(i + 1) > iters) iters = (unsigned long long)(i + 1);
       }
     }
     stats_out[0] = so; stats_out[1] = ev; stats_out[2] = sc; stats_out[3] = in; stats_out[4] = nf;

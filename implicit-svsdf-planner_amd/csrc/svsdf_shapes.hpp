@@ -26,12 +26,21 @@ struct ShapeParams {
   double r00, r01, r10, r11;  // Rotate                      SHP:287-292
   double c0x, c0y;            // shape-specific (cos,sin) pair: horseshoe c / pie c / arc sc
   double r_bound;             // conservative circumradius about the body-frame origin (culling)
+  int identity;               // trans == 0 and Rotate == I (poly_params = 0): the transform is exact identity
   int nverts;                 // Polygon
   const double *verts;        // Polygon: device pointer, xy interleaved
 };
 
-__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }  // std::max
-__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }  // std::min
+// std::max / std::min.  Strict builds keep the compare+select form; the default uses v_max_f64 /
+// v_min_f64, which return the same value for every non-NaN input (only the sign of a zero result
+// can differ when the operands are zeros of opposite sign, which no formula here distinguishes).
+#ifdef SVSDF_SELECT_MINMAX
+__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
+#else
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+#endif
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return dmax(dmin(v, hi), lo); }
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
 
@@ -264,9 +273,12 @@ __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, dou
   if constexpr (SHAPE == kPolygon) {
     return sdf_polygon(sp, x, y, nullptr, nullptr);
   } else {
-    const double dx = x - sp.tx, dy = y - sp.ty;
-    const double px = dx * sp.r00 + dy * sp.r10;
-    const double py = dx * sp.r01 + dy * sp.r11;
+    double px = x, py = y;
+    if (!sp.identity) {  // wave-uniform; with trans = 0, Rotate = I the products below are exact no-ops
+      const double dx = x - sp.tx, dy = y - sp.ty;
+      px = dx * sp.r00 + dy * sp.r10;
+      py = dx * sp.r01 + dy * sp.r11;
+    }
     if constexpr (SHAPE == kUnevenCapsule) return sdf_uneven_capsule(px, py);
     else if constexpr (SHAPE == kCutDisk) return sdf_cut_disk(px, py);
     else if constexpr (SHAPE == kTrapezoid) return sdf_trapezoid(px, py);

@@ -171,8 +171,8 @@ typedef struct svsdf_stats {
   unsigned long long sdf_evals;       /* SDF-at-time evaluations executed on the device */
   unsigned long long scan_evals;      /* of which layer-1 table evaluations */
   double device_ms;                   /* HIP-event time of the whole device pipeline (profiling on) */
-  double solve_ms;                    /* HIP-event time summed over the k_refine launches (profiling on) */
-  unsigned int solve_launches;        /* k_refine launches of the last evaluation */
+  double solve_ms;                    /* HIP-event time summed over the k_solve launches (profiling on) */
+  unsigned int solve_launches;        /* k_solve launches of the last evaluation */
   unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
