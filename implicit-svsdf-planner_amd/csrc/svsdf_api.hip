@@ -60,9 +60,10 @@ struct svsdf_ctx {
   int N = 0, K = 0;
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
-  int G = 4, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
-  int late_iter = 4, first_iters = 12, it_done = 0, U = 1;
+  int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
+  int late_iter = 4, first_iters = 12, it_done = 0, U = 1, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
+  int G_env = 0;
   double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
   // per-point / per-sub-query buffers
@@ -213,14 +214,29 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
 
 void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const long long pts = std::max(1, ctx->bcount[b]);
-  const unsigned grid = (unsigned)std::min<long long>((pts * 32 + kRoundBlock - 1) / kRoundBlock, 1024);
   const size_t lds = table_lds_doubles(ctx) * sizeof(double);
-#define CALL(S)                                                                                          \
-  hipLaunchKernelGGL((k_round<S>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,      \
-                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, ctx->select_delta, \
+  // late iterations hold few points and are latency-bound: request every sample there, which
+  // avoids supplementary iterations at no cost in time
+  const double delta = (it >= ctx->delta_all_iter) ? 1e300 : ctx->select_delta;
+  // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per
+  // point; later rounds have 18-21 samples: 32 lanes per point (either handles any count)
+  if (it < ctx->round_lp8_iters) {
+    const unsigned grid = (unsigned)std::min<long long>((pts * 8 + kRoundBlock - 1) / kRoundBlock, 1024);
+#define CALL(S)                                                                                           \
+  hipLaunchKernelGGL((k_round<S, 8>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,   \
+                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, \
                      ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
-  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+    SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
+  } else {
+    const unsigned grid = (unsigned)std::min<long long>((pts * 32 + kRoundBlock - 1) / kRoundBlock, 1024);
+#define CALL(S)                                                                                           \
+  hipLaunchKernelGGL((k_round<S, 32>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,  \
+                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, \
+                     ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
+    SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+  }
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
@@ -524,6 +540,9 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;  // multi-stream batches (SVSDF_BATCHES) measured inconsistent across boxes
   nb = std::max(1, std::min(nb, kMaxBatches));
   ctx->nbatch = nb;
+  // lanes per query: 8 keeps the dependent chains short while a shard cannot fill the GPU anyway;
+  // 4 wastes fewer lanes once throughput matters (measured crossover ~3e5 points)
+  if (!ctx->G_env) ctx->G = (Ps < 300000) ? 8 : 4;
   std::vector<BatchCtl> hc(kMaxBatches);
   std::memset(hc.data(), 0, sizeof(BatchCtl) * kMaxBatches);
   for (int b = 0; b < nb; ++b) {
@@ -634,12 +653,15 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     sp.verts = ctx->d_poly;
     ctx->cfg.polygon_nverts = sp.nverts;
   }
-  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) { ctx->G = g; ctx->G_late = std::max(g, 8); } }
+  ctx->G_env = 0;
+  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
   if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) ctx->G_late = g; }
   if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
+  if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) ctx->delta_all_iter = std::atoi(e);
+  if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_U")) ctx->U = std::atoi(e) == 2 ? 2 : 1;
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) ctx->select_delta = std::atof(e);
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
@@ -769,6 +791,19 @@ int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double
     for (size_t j = 0; j < P; ++j) { grad_xy[2 * j] = gx[j]; grad_xy[2 * j + 1] = gy[j]; }
   }
   return SVSDF_OK;
+}
+
+long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, int n) {
+  if (!ctx || ctx->host_only || n < 2) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_out);
+  if (hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_sincos_check, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, lo, hi, n, d);
+  unsigned long long h = 0;
+  if (hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return -1;
+  return (long long)h;
 }
 
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {

@@ -27,6 +27,9 @@
 
 namespace svsdf {
 
+#ifndef SVSDF_SOLVE_WAVES
+#define SVSDF_SOLVE_WAVES 1
+#endif
 constexpr int kMaxPieces = 64;
 constexpr int kMaxSlots = 24;   // GSIP samples per round: 2, 6, 18, 21, 21, ... (SWM:60-71,105-110)
 constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
@@ -126,6 +129,76 @@ __device__ __forceinline__ void piece_vel(const double *__restrict__ c, double s
   }
 }
 
+// sincos for |a| < 2^30: the exact operation sequence of the ROCm device library's
+// __ocml_sincos_f64 (trigredsmall + sincosred2 + quadrant selection, ROCm 7.2 ocml.bc) written
+// out so that it inlines without the large-argument (Payne-Hanek) branch and the inf/nan
+// handling; bit-identical results (checked on device by svsdf_debug_sincos_mismatches).
+// Larger arguments take the library routine.
+__device__ __forceinline__ void sincos_exact(double a, double *sn, double *cs) {
+  const double ax = fabs(a);
+  if (!(ax < 0x1p30)) { sincos(a, sn, cs); return; }
+  // __ocmlpriv_trigredsmall_f64
+  const double r = rint(ax * 0x1.45f306dc9c883p-1);
+  const double t4 = __builtin_fma(r, -0x1.921fb54442d18p+0, ax);
+  const double t5 = __builtin_fma(r, -0x1.1a62633145c00p-54, t4);
+  const double t6 = r * 0x1.1a62633145c00p-54;
+  const double t8 = __builtin_fma(r, 0x1.1a62633145c00p-54, -t6);
+  const double t9 = t4 - t6;
+  const double t10 = t4 - t9;
+  const double t11 = t10 - t6;
+  const double t12 = t9 - t5;
+  const double t13 = t12 + t11;
+  const double t14 = t13 - t8;
+  const double t15 = __builtin_fma(r, -0x1.b839a252049c0p-104, t14);
+  const double x = t5 + t15;            // reduced argument, high part
+  const double y = t15 - (x - t5);      // low part
+  const int q = (int)r & 3;
+  // __ocmlpriv_sincosred2_f64(x, y)
+  const double s = x * x;
+  const double h = s * 0.5;
+  const double u5 = 1.0 - h;
+  const double u7 = (1.0 - u5) - h;
+  const double s2 = s * s;
+  double pc = __builtin_fma(s, -0x1.907db46cc5e42p-37, 0x1.1eeb69037ab78p-29);
+  pc = __builtin_fma(s, pc, -0x1.27e4fa17f65f6p-22);
+  pc = __builtin_fma(s, pc, 0x1.a01a019f4ec90p-16);
+  pc = __builtin_fma(s, pc, -0x1.6c16c16c16967p-10);
+  pc = __builtin_fma(s, pc, 0x1.5555555555555p-5);
+  const double ny = -y;
+  const double c15 = __builtin_fma(x, ny, u7);
+  const double c16 = __builtin_fma(s2, pc, c15);
+  const double cv = u5 + c16;
+  double ps = __builtin_fma(s, 0x1.5e0b2f9a43bb8p-33, -0x1.ae600b42fdfa7p-26);
+  ps = __builtin_fma(s, ps, 0x1.71de3796cde01p-19);
+  ps = __builtin_fma(s, ps, -0x1.a01a019e83e5cp-13);
+  ps = __builtin_fma(s, ps, 0x1.1111111110bb3p-7);
+  const double xs = x * (-s);
+  const double s25 = __builtin_fma(xs, ps, y * 0.5);
+  const double s26 = __builtin_fma(s, s25, ny);
+  const double s27 = __builtin_fma(xs, -0x1.5555555555555p-3, s26);
+  const double sv = x - s27;
+  // quadrant selection of __ocml_sincos_f64
+  const int flip = (q > 1) ? (int)0x80000000 : 0;
+  const bool even = (q & 1) == 0;
+  const double so = even ? sv : cv;
+  const double co = even ? cv : -sv;
+  const int sgn_in = __double2hiint(a) & (int)0x80000000;
+  *sn = __hiloint2double(__double2hiint(so) ^ sgn_in ^ flip, __double2loint(so));
+  *cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
+}
+
+// mismatch counter for sincos_exact vs the library sincos (diagnostics / test only)
+__global__ void k_sincos_check(double lo, double hi, int n, unsigned long long *mism) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = lo + (hi - lo) * ((double)i / (double)(n - 1));
+  double s0, c0, s1, c1;
+  sincos(a, &s0, &c0);
+  sincos_exact(a, &s1, &c1);
+  if (__double_as_longlong(s0) != __double_as_longlong(s1) || __double_as_longlong(c0) != __double_as_longlong(c1))
+    atomicAdd(mism, 1ull);
+}
+
 // per-lane cache of the current piece and its [S_lo, S_hi] interval (avoids the LDS walk when
 // consecutive evaluations stay in one piece, which is the rule in the scan layers and the descent)
 struct PieceCache {
@@ -147,7 +220,7 @@ __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, PieceCache &p
   piece_pos(tr.c + piece * 18, s, x, y, yaw);
   Pose p;
   p.x = x; p.y = y;
-  sincos(yaw, &p.sn, &p.cs);
+  sincos_exact(yaw, &p.sn, &p.cs);
   return p;
 }
 
@@ -348,7 +421,7 @@ __device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wav
 // LDS: [pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
 // ---------------------------------------------------------------------------------------------
 template <int SHAPE, int G, int U>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, SVSDF_SOLVE_WAVES)
 k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
         double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx) {
@@ -694,19 +767,23 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
 // Opening a round: SampleSet2D::getElements / getElementPos (SWM:36-39, 60-71; one ring rk = 1)
 // with theta_j = theta0 + j * theta_res by repeated addition; expandSet(2, theta*) (SWM:105-110).
 // ---------------------------------------------------------------------------------------------
-constexpr int kRoundBlock = 1024;  // 32 points per block: one set of list atomics per 32 points
-template <int SHAPE>
+// LP lanes per point (8 or 32): the early rounds have 2 and 6 samples, the later ones 18-21; a
+// point with more samples than lanes is handled in ceil(n / LP) passes.
+constexpr int kRoundBlock = 1024;
+template <int SHAPE, int LP>
 __global__ void __launch_bounds__(kRoundBlock)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
         const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta,
         double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx,
         double *__restrict__ res_gy, BatchCtl *__restrict__ ctl) {
+  static_assert(LP == 8 || LP == 32, "lanes per point");
+  constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   extern __shared__ double round_lds[];
-  __shared__ int s_cnt[3][kRoundBlock / 32];   // per half-wave: solves, next-list entries, samples
-  __shared__ int s_base[2][kRoundBlock / 32];  // per half-wave: solve-list / next-list positions
+  __shared__ int s_cnt[3][kRoundBlock / LP];   // per point slot: solves, next-list entries, samples
+  __shared__ int s_base[2][kRoundBlock / LP];  // per point slot: solve-list / next-list positions
   const int n_act = ctl->n_active[it];
-  const int ppb = blockDim.x / 32;  // points per block
+  const int ppb = blockDim.x / LP;  // points per block
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
@@ -723,21 +800,25 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   const int *cur = gs.list[it & 1] + start;
   int *nxt = gs.list[(it + 1) & 1] + start;
   int *solve = gs.solve + (size_t)start * kMaxSlots;
-  const int l = (int)(threadIdx.x & 31);
-  const int hw = (int)(threadIdx.x >> 5);
+  const int l = (int)(threadIdx.x & (LP - 1));
+  const int hw = (int)(threadIdx.x / LP);
   const unsigned lt_mask = (1u << l) - 1u;
-  auto ballot32 = [&](bool p) -> unsigned {
+  auto ballot_g = [&](bool p) -> unsigned {   // bit i <=> lane i of this point's lane group
     const unsigned long long m = __ballot(p);
-    return (unsigned)(((threadIdx.x & 32) ? (m >> 32) : m) & 0xffffffffull);
+    const int base = (int)(threadIdx.x & 63) & ~(LP - 1);
+    return (unsigned)((m >> base) & ((LP == 32) ? 0xffffffffull : 0xffull));
   };
-  // block-uniform trip count; half-waves without a point still take part in the barriers
+  // block-uniform trip count; lane groups without a point still take part in the barriers
   for (int e0 = (int)blockIdx.x * ppb; e0 < n_act; e0 += (int)gridDim.x * ppb) {
     const int e = e0 + hw;
     const bool active = e < n_act;
-    int a = 0, i = 0, n_emit = 0;
+    int a = 0, i = 0, n_emit = 0, n_list = 0;
     size_t ia = 0;
-    bool push_next = false, open = false, list_me = false;  // list_me: this lane adds its slot
-    unsigned mlist = 0u;                                     // lanes of the half-wave adding slots
+    bool push_next = false, open = false;
+    bool list_me[NP];
+    unsigned mlist[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) { list_me[ps] = false; mlist[ps] = 0u; }
     double cx = 0.0, cy = 0.0, r = 0.0, theta0 = 0.0, theta_res = 0.0;
     if (active) {
       a = cur[e];
@@ -749,15 +830,19 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
       if (!open) {
         // ---- close the round: max over the solved samples, first index wins ties (strict >)
         const int n = gs.nsamp[ia];
-        const size_t s = (size_t)l * stride + ia;
-        const bool has = l < n;
-        const double g_l = has ? gs.sq_sdf[s] : kUnsolved;
-        double g = g_l;
-        int idx = l;
+        double g_mine[NP];
+        double g = kUnsolved;
+        int idx = 0x7fffffff;
 #pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) {
-          const double og = __shfl_xor(g, m, 32);
-          const int oi = __shfl_xor(idx, m, 32);
+        for (int ps = 0; ps < NP; ++ps) {
+          const int j = l + LP * ps;
+          g_mine[ps] = (j < n) ? gs.sq_sdf[(size_t)j * stride + ia] : kUnsolved;
+          if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
+        }
+#pragma unroll
+        for (int m = LP / 2; m >= 1; m >>= 1) {
+          const double og = __shfl_xor(g, m, LP);
+          const int oi = __shfl_xor(idx, m, LP);
           if (og > g || (og == g && oi < idx)) { g = og; idx = oi; }
         }
         double max_g = -100000, real_t = res_t[i], star_th = 0.0;
@@ -766,10 +851,16 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
           max_g = g; real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
         }
         // unsolved samples that could still reach max_g -> supplementary solves
-        const bool need = has && g_l == kUnsolved && gs.sq_ub[s] >= max_g;
-        const unsigned mneed = ballot32(need);
-        if (mneed != 0u) {
-          list_me = need; mlist = mneed; push_next = true;
+        bool any = false;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+          const int j = l + LP * ps;
+          list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gs.sq_ub[(size_t)j * stride + ia] >= max_g;
+          mlist[ps] = ballot_g(list_me[ps]);
+          any = any || (mlist[ps] != 0u);
+        }
+        if (any) {
+          push_next = true;
           if (l == 0) gs.phase[ia] = kPhaseSupp;
         } else {
           const double r_star = r - max_g;
@@ -798,56 +889,81 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         }
       }
       if (open) {
-        // ---- open a round: lane l <-> sample l
+        // ---- open a round: lane l takes samples l, l + LP, ...
         double theta = theta0;
         for (int q = 0; q < l; ++q) theta += theta_res;
-        const bool valid = (theta < theta0 + 2 * kPI) && (l < kMaxSlots);
-        const unsigned mvalid = ballot32(valid);
-        n_emit = __popc(mvalid);  // theta increases with l: the valid lanes are a prefix
-        const size_t s = (size_t)l * stride + ia;
-        double ub = -1e300;
-        if (valid) {
-          const double qx = cx + 1.0 * r * cos(theta);
-          const double qy = cy + 1.0 * r * sin(theta);
-          // cheap upper bound: best table pose of the chunk whose bounding circle is nearest
-          double d2min = 1e300;  // any chunk gives a valid bound: take the nearest centre
-          int c0 = 0;
-          for (int c = 0; c < nch; ++c) {
-            const Chunk ch = chunks[c];
-            const double ex = qx - ch.cx, ey = qy - ch.cy;
-            const double d2 = ex * ex + ey * ey;
-            if (d2 < d2min) { d2min = d2; c0 = c; }
-          }
-          ub = 1e300;
-          const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
-          for (int k = c0 * kChunk; k < k1; ++k) ub = dmin(ub, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
-          gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_ub[s] = ub; gs.sq_sdf[s] = kUnsolved;
-        }
-        double umax = ub;
+        double ub[NP], umax = -1e300;
+        bool valid[NP];
 #pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) umax = fmax(umax, __shfl_xor(umax, m, 32));
-        list_me = valid && ub >= umax - delta;
-        mlist = ballot32(list_me);
+        for (int ps = 0; ps < NP; ++ps) {
+          const int j = l + LP * ps;
+          valid[ps] = (theta < theta0 + 2 * kPI) && (j < kMaxSlots);
+          n_emit += __popc(ballot_g(valid[ps]));  // theta increases with j: the valid samples are a prefix
+          ub[ps] = -1e300;
+          if (valid[ps]) {
+            const size_t s = (size_t)j * stride + ia;
+            const double qx = cx + 1.0 * r * cos(theta);
+            const double qy = cy + 1.0 * r * sin(theta);
+            // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
+            double d2min = 1e300;
+            int c0 = 0;
+            for (int c = 0; c < nch; ++c) {
+              const Chunk ch = chunks[c];
+              const double ex = qx - ch.cx, ey = qy - ch.cy;
+              const double d2 = ex * ex + ey * ey;
+              if (d2 < d2min) { d2min = d2; c0 = c; }
+            }
+            double u = 1e300;
+            const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
+            for (int k = c0 * kChunk; k < k1; ++k) u = dmin(u, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
+            ub[ps] = u;
+            gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_ub[s] = u; gs.sq_sdf[s] = kUnsolved;
+          }
+          umax = fmax(umax, ub[ps]);
+          if (ps + 1 < NP) {
+#pragma unroll
+            for (int q = 0; q < LP; ++q) theta += theta_res;
+          }
+        }
+#pragma unroll
+        for (int m = LP / 2; m >= 1; m >>= 1) umax = fmax(umax, __shfl_xor(umax, m, LP));
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+          list_me[ps] = valid[ps] && ub[ps] >= umax - delta;
+          mlist[ps] = ballot_g(list_me[ps]);
+        }
         push_next = true;
         if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = kPhaseEval; }
       }
     }
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) n_list += __popc(mlist[ps]);
     // ---- one set of list atomics per block iteration
-    if (l == 0) { s_cnt[0][hw] = __popc(mlist); s_cnt[1][hw] = push_next ? 1 : 0; s_cnt[2][hw] = n_emit; }
+    if (l == 0) { s_cnt[0][hw] = n_list; s_cnt[1][hw] = push_next ? 1 : 0; s_cnt[2][hw] = n_emit; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {  // one wave: exclusive scans over the <= 128 point slots of the block
       int t0 = 0, t1 = 0, t2 = 0;
-      for (int h = 0; h < ppb; ++h) {
-        s_base[0][h] = t0; s_base[1][h] = t1;
-        t0 += s_cnt[0][h]; t1 += s_cnt[1][h]; t2 += s_cnt[2][h];
+      for (int h = (int)threadIdx.x; h < ppb; h += 64) { t0 += s_cnt[0][h]; t1 += s_cnt[1][h]; t2 += s_cnt[2][h]; }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) { t0 += __shfl_xor(t0, m, 64); t1 += __shfl_xor(t1, m, 64); t2 += __shfl_xor(t2, m, 64); }
+      int b0 = 0, b1 = 0;
+      if (threadIdx.x == 0) {
+        b0 = t0 ? atomicAdd(&ctl->n_solve[it], t0) : 0;
+        b1 = t1 ? atomicAdd(&ctl->n_active[it + 1], t1) : 0;
+        if (t2) atomicAdd(&ctl->n_seed[it], t2);
+        int r0 = b0, r1 = b1;
+        for (int h = 0; h < ppb; ++h) { s_base[0][h] = r0; s_base[1][h] = r1; r0 += s_cnt[0][h]; r1 += s_cnt[1][h]; }
       }
-      const int b0 = t0 ? atomicAdd(&ctl->n_solve[it], t0) : 0;
-      const int b1 = t1 ? atomicAdd(&ctl->n_active[it + 1], t1) : 0;
-      if (t2) atomicAdd(&ctl->n_seed[it], t2);
-      for (int h = 0; h < ppb; ++h) { s_base[0][h] += b0; s_base[1][h] += b1; }
     }
     __syncthreads();
-    if (list_me) solve[s_base[0][hw] + __popc(mlist & lt_mask)] = (int)((size_t)l * stride + ia);
+    {
+      int pos = s_base[0][hw];
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        if (list_me[ps]) solve[pos + __popc(mlist[ps] & lt_mask)] = (int)((size_t)(l + LP * ps) * stride + ia);
+        pos += __popc(mlist[ps]);
+      }
+    }
     if (push_next && l == 0) nxt[s_base[1][hw]] = a;
     __syncthreads();
   }

@@ -22,7 +22,7 @@ EXPORTS = [
     "svsdf_accumulate_partial", "svsdf_lmbm_evaluate", "svsdf_last_costs", "svsdf_lmbm_begin",
     "svsdf_lmbm_finish", "svsdf_minco_coeffs", "svsdf_forward_T", "svsdf_backward_T",
     "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices", "svsdf_set_profiling",
-    "svsdf_shard_plan", "svsdf_lmbm_prepare",
+    "svsdf_shard_plan", "svsdf_lmbm_prepare", "svsdf_debug_sincos_mismatches",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
     L.svsdf_shard_plan.argtypes = [_dp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong),
                                    C.POINTER(C.c_size_t)]
     L.svsdf_lmbm_prepare.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp]
+    L.svsdf_debug_sincos_mismatches.restype = C.c_longlong
+    L.svsdf_debug_sincos_mismatches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
     _LIB = L
     return L
 
@@ -297,6 +299,9 @@ class SvsdfContext:
         idx = self.shard_indices()
         order = np.argsort(idx, kind="stable")
         return sdf[order], ts[order], g[order], idx[order]
+
+    def sincos_mismatches(self, lo, hi, n):
+        return int(self.L.svsdf_debug_sincos_mismatches(self.ctx, float(lo), float(hi), int(n)))
 
     def set_profiling(self, enable=True):
         self._chk(self.L.svsdf_set_profiling(self.ctx, int(bool(enable))), "svsdf_set_profiling")

@@ -179,6 +179,9 @@ int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 /* Per-launch HIP-event timing of the dominant (argmin refine) kernel on the library's own
  * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms. */
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable);
+/* Self-check: number of n equispaced arguments in [lo, hi] for which the kernels' inlined sincos
+ * differs by even one bit from the ROCm device library's sincos (must be 0); -1 on error. */
+long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, int n);
 /* Original indices (into the array given to svsdf_set_points) of this rank's shard, in the
  * order svsdf_query_points reports them. */
 int svsdf_shard_indices(const svsdf_ctx *ctx, long long *idx_out);

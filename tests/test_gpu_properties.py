@@ -113,3 +113,15 @@ def test_million_points_far_points_contribute_exact_zero(built, config):
     z = c.eval_penalty(w["coeffs"], w["T"])
     assert z[0] == 0.0 and not z[1].any() and not z[2].any()
     c.close()
+
+
+def test_inlined_sincos_is_bit_identical_to_device_library(built):
+    """The kernels inline the ROCm device library's sincos arithmetic (small-argument path);
+    every result bit must agree with the library routine, including arguments around the
+    2^30 hand-over and negative / tiny / zero arguments."""
+    import svsdf_amd
+    c = svsdf_amd.SvsdfContext(shape="star", device=0)
+    for lo, hi, n in ((-10.0, 10.0, 4_000_001), (-1e-300, 1e-300, 1001), (-4000.0, 4000.0, 2_000_001),
+                      (1.0e9, 1.2e9, 100_001), (-3.0e10, 3.0e10, 100_001), (0.0, 0.0 + 1e-12, 1001)):
+        assert c.sincos_mismatches(lo, hi, n) == 0, (lo, hi)
+    c.close()
