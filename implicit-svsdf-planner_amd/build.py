@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "svsdf_api.hip")
 DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("svsdf_api.hip", "svsdf_kernels.hpp", "svsdf_shapes.hpp", "svsdf_minco.hpp")] + \
+        ("svsdf_api.hip", "svsdf_kernels.hpp", "svsdf_shapes.hpp", "svsdf_minco.hpp", "svsdf_points.hpp")] + \
        [os.path.join(HERE, "..", "include", "svsdf_c.h")]
 OUT = os.path.join(HERE, "libsvsdf_hip.so")
 

@@ -20,6 +20,7 @@
 #include "../../include/svsdf_c.h"
 #include "svsdf_kernels.hpp"
 #include "svsdf_minco.hpp"
+#include "svsdf_points.hpp"
 
 using namespace svsdf;
 
@@ -815,6 +816,52 @@ int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out) {
   if (!ctx || !out) return SVSDF_ERR_INVALID;
   *out = ctx->stats;
+  return SVSDF_OK;
+}
+
+// ---- query-point producer (host) -----------------------------------------------------------------
+struct svsdf_map {
+  svsdf_host::OccupancyMap m;
+};
+
+svsdf_map *svsdf_map_create(const float *xyz, size_t n, double resolution, int sta_threshold) {
+  if ((!xyz && n) || !(resolution > 0.0)) return nullptr;
+  svsdf_map *mp = new svsdf_map();
+  mp->m.build(xyz, n, resolution, sta_threshold);
+  return mp;
+}
+void svsdf_map_destroy(svsdf_map *map) { delete map; }
+int svsdf_map_info(const svsdf_map *map, int dims[3], double bmin[3], double bmax[3], size_t *occupied) {
+  if (!map) return SVSDF_ERR_INVALID;
+  for (int d = 0; d < 3; ++d) {
+    if (dims) dims[d] = map->m.dims()[d];
+    if (bmin) bmin[d] = map->m.bmin()[d];
+    if (bmax) bmax[d] = map->m.bmax()[d];
+  }
+  if (occupied) *occupied = map->m.occupied_count();
+  return SVSDF_OK;
+}
+int svsdf_map_gather(const svsdf_map *map, const double *centres_xyz, size_t ncentres, const double halfbd[3],
+                     double *out_xyz, size_t capacity, size_t *count) {
+  if (!map || (!centres_xyz && ncentres) || !halfbd || !count) return SVSDF_ERR_INVALID;
+  std::vector<double> pts;
+  map->m.gather(centres_xyz, ncentres, halfbd, pts);
+  *count = pts.size() / 3;
+  if (out_xyz) {
+    if (capacity < *count) return SVSDF_ERR_INVALID;
+    std::copy(pts.begin(), pts.end(), out_xyz);
+  }
+  return SVSDF_OK;
+}
+int svsdf_pcd_read_ascii(const char *path, float *xyz, size_t capacity, size_t *n) {
+  if (!path || !n) return SVSDF_ERR_INVALID;
+  std::vector<float> v;
+  if (!svsdf_host::read_pcd_ascii(path, v)) return SVSDF_ERR_INVALID;
+  *n = v.size() / 3;
+  if (xyz) {
+    if (capacity < *n) return SVSDF_ERR_INVALID;
+    std::copy(v.begin(), v.end(), xyz);
+  }
   return SVSDF_OK;
 }
 

@@ -7,10 +7,10 @@ library or a GPU is missing.
 """
 from .binding import (SHAPES, SHAPE_ID, SvsdfError, SvsdfContext, lib, lib_path, minco_coeffs,
                       forward_T, backward_T, shape_id_from_inputdata, shard_plan,
-                      FLAG_HOST_ONLY, FLAG_KEEP_INPUT_ORDER)
+                      FLAG_HOST_ONLY, FLAG_KEEP_INPUT_ORDER, OccupancyMap)
 from .traj_optimizer import TrajOptimizer
 from . import workload
 
 __all__ = ["SHAPES", "SHAPE_ID", "SvsdfError", "SvsdfContext", "TrajOptimizer", "lib", "lib_path",
            "minco_coeffs", "forward_T", "backward_T", "shape_id_from_inputdata", "shard_plan",
-           "FLAG_HOST_ONLY", "FLAG_KEEP_INPUT_ORDER", "workload"]
+           "FLAG_HOST_ONLY", "FLAG_KEEP_INPUT_ORDER", "OccupancyMap", "workload"]

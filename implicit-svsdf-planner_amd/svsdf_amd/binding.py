@@ -23,6 +23,7 @@ EXPORTS = [
     "svsdf_lmbm_finish", "svsdf_minco_coeffs", "svsdf_forward_T", "svsdf_backward_T",
     "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices", "svsdf_set_profiling",
     "svsdf_shard_plan", "svsdf_lmbm_prepare", "svsdf_debug_sincos_mismatches",
+    "svsdf_map_create", "svsdf_map_destroy", "svsdf_map_info", "svsdf_map_gather", "svsdf_pcd_read_ascii",
 ]
 
 
@@ -95,6 +96,13 @@ def lib():
     L.svsdf_shard_plan.argtypes = [_dp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong),
                                    C.POINTER(C.c_size_t)]
     L.svsdf_lmbm_prepare.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp]
+    _fp = C.POINTER(C.c_float)
+    L.svsdf_map_create.restype = C.c_void_p
+    L.svsdf_map_create.argtypes = [_fp, C.c_size_t, C.c_double, C.c_int]
+    L.svsdf_map_destroy.argtypes = [C.c_void_p]
+    L.svsdf_map_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_size_t)]
+    L.svsdf_map_gather.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.svsdf_pcd_read_ascii.argtypes = [C.c_char_p, _fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.svsdf_debug_sincos_mismatches.restype = C.c_longlong
     L.svsdf_debug_sincos_mismatches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
     _LIB = L
@@ -143,6 +151,55 @@ def backward_T(T):
     tau = np.zeros_like(T)
     lib().svsdf_backward_T(_p(T), _p(tau), len(T))
     return tau
+
+
+class OccupancyMap:
+    """Host-side query-point producer (PCSmapManager + the plan_manager waypoint loop)."""
+
+    def __init__(self, cloud_xyz, resolution=1.0, sta_threshold=1):
+        self.L = lib()
+        pts = np.ascontiguousarray(cloud_xyz, dtype=np.float32).reshape(-1, 3)
+        h = self.L.svsdf_map_create(pts.ctypes.data_as(C.POINTER(C.c_float)), len(pts), float(resolution), int(sta_threshold))
+        if not h:
+            raise SvsdfError("svsdf_map_create failed")
+        self.h = C.c_void_p(h)
+
+    @staticmethod
+    def read_pcd(path):
+        L = lib()
+        n = C.c_size_t()
+        if L.svsdf_pcd_read_ascii(path.encode(), None, 0, C.byref(n)):
+            raise SvsdfError(f"cannot read {path} as ASCII PCD (FIELDS x y z)")
+        xyz = np.zeros((n.value, 3), dtype=np.float32)
+        L.svsdf_pcd_read_ascii(path.encode(), xyz.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n))
+        return xyz
+
+    def info(self):
+        dims = (C.c_int * 3)()
+        bmin, bmax = np.zeros(3), np.zeros(3)
+        occ = C.c_size_t()
+        self.L.svsdf_map_info(self.h, dims, _p(bmin), _p(bmax), C.byref(occ))
+        return dict(dims=tuple(dims), bmin=bmin, bmax=bmax, occupied=occ.value)
+
+    def gather(self, centres, halfbd):
+        c = _f64(centres).reshape(-1, 3)
+        hb = _f64(halfbd).reshape(3)
+        n = C.c_size_t()
+        rc = self.L.svsdf_map_gather(self.h, _p(c), len(c), _p(hb), None, 0, C.byref(n))
+        if rc:
+            raise SvsdfError(f"svsdf_map_gather failed: {rc}")
+        out = np.zeros((n.value, 3))
+        if n.value:
+            self.L.svsdf_map_gather(self.h, _p(c), len(c), _p(hb), _p(out), n.value, C.byref(n))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.svsdf_map_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 FLAG_KEEP_INPUT_ORDER = 1

@@ -149,6 +149,23 @@ int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial,
 int svsdf_lmbm_prepare(svsdf_ctx *ctx, const double *x, int n, double *coeffs_out, double *T_out);
 double svsdf_lmbm_finish(svsdf_ctx *ctx, const double *partial_host, double *g, int n);
 
+/* ---- query-point producer (host) ------------------------------------------------ */
+/* Replaces, for the data this path consumes, PCSmapManager::rcvGlobalMapHandler
+ * (src/map_manager/src/PCSmap_manager.cpp:88-210: cloud -> bounds -> occupancy grid with
+ * `sta_threshold`) and the waypoint loop around getPointsInAABBOutOfLastOne
+ * (src/plan_manager/src/plan_manager.cpp:156-175, PCSmap_manager.h:184-219).  xyz are float32
+ * like pcl::PointXYZ.  svsdf_map_gather returns the occupied-voxel centres (deduplicated, ordered
+ * by the reference's unified voxel id) ready for svsdf_set_points; out_xyz may be NULL to query
+ * the count. */
+typedef struct svsdf_map svsdf_map;
+svsdf_map *svsdf_map_create(const float *xyz, size_t n, double resolution, int sta_threshold);
+void svsdf_map_destroy(svsdf_map *map);
+int svsdf_map_info(const svsdf_map *map, int dims[3], double bmin[3], double bmax[3], size_t *occupied);
+int svsdf_map_gather(const svsdf_map *map, const double *centres_xyz, size_t ncentres, const double halfbd[3],
+                     double *out_xyz, size_t capacity, size_t *count);
+/* ASCII PCD v0.7, FIELDS x y z (src/plan_manager/pcds/map_*.pcd); xyz may be NULL to query n. */
+int svsdf_pcd_read_ascii(const char *path, float *xyz, size_t capacity, size_t *n);
+
 /* ---- host-side MINCO helpers (MNC:397-655) ------------------------------------------------------- */
 /* waypoints inPs: 3 x (N-1) col-major; out coeffs (6N) x 3 col-major. */
 int svsdf_minco_coeffs(const double head_state[9], const double tail_state[9], int N,

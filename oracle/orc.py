@@ -68,6 +68,9 @@ def lib():
     L.orc_smoothed_l1.argtypes = [C.c_double, C.c_double, _dp, _dp]
     L.orc_shape_id_from_name.restype = C.c_int
     L.orc_shape_id_from_name.argtypes = [C.c_char_p]
+    L.orc_map_points.restype = C.c_size_t
+    L.orc_map_points.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp,
+                                 C.c_size_t, C.POINTER(C.c_int)]
     _LIB = L
     return L
 
@@ -228,3 +231,17 @@ def smoothed_l1(x, mu=0.01):
     f, df = C.c_double(0.0), C.c_double(0.0)
     ok = lib().orc_smoothed_l1(x, mu, C.byref(f), C.byref(df))
     return bool(ok), f.value, df.value
+
+
+def map_points(cloud, centres, halfbd, resolution=1.0, sta_threshold=1):
+    """Query-point producer (PCSmapManager + plan_manager waypoint loop): returns (points (n,3), dims)."""
+    L = lib()
+    cl = np.ascontiguousarray(cloud, dtype=np.float32).reshape(-1, 3)
+    c = _f64(centres).reshape(-1, 3)
+    hb = _f64(halfbd).reshape(3)
+    dims = (C.c_int * 3)()
+    cap = 1 << 22
+    out = np.zeros((cap, 3))
+    n = L.orc_map_points(cl.ctypes.data_as(C.POINTER(C.c_float)), len(cl), float(resolution), int(sta_threshold),
+                         _p(c), len(c), _p(hb), _p(out), cap, dims)
+    return out[:n].copy(), tuple(dims)

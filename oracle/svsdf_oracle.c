@@ -1158,3 +1158,103 @@ double orc_cost_function(orc_ctx *ctx, const double *xyz, size_t P, int nthreads
   minco_free(&m);
   return cost;
 }
+
+/* ------------------------------------------------------------------------- */
+/* query-point producer                                                       */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  double res, bmin[3], bmax[3];
+  int X, Y, Z;
+  double *grid; /* counts, then 0/1 */
+} orc_grid;
+
+static int grid_in_map(const orc_grid *g, const double p[3]) { /* Gridmap3D.cpp:43-71 */
+  for (int d = 0; d < 3; ++d)
+    if (p[d] < g->bmin[d] || p[d] > g->bmax[d]) return 0;
+  return 1;
+}
+static void grid_index(const orc_grid *g, const double p[3], int id[3]) { /* Gridmap3D.cpp:137-177 */
+  if (!grid_in_map(g, p)) { id[0] = id[1] = id[2] = 0; return; }
+  int ix = (int)floor((p[0] - g->bmin[0]) / g->res);
+  int iy = (int)floor((p[1] - g->bmin[1]) / g->res);
+  int iz = (int)floor((p[2] - g->bmin[2]) / g->res);
+  if (ix < 0) ix = 0;
+  if (ix >= g->X) ix = g->X - 1;
+  if (iy < 0) ix = 0; /* sic */
+  if (iy >= g->Y) iy = g->Y - 1;
+  if (iz < 0) ix = 0; /* sic */
+  if (iz >= g->Z) iz = g->Z - 1;
+  id[0] = ix; id[1] = iy; id[2] = iz;
+}
+static int grid_addr(const orc_grid *g, int i, int j, int k) { return i * g->Y * g->Z + j * g->Z + k; }
+static int grid_occupied(const orc_grid *g, int i, int j, int k) { /* Gridmap3D.cpp:239-283 */
+  if (i < 0 || i >= g->X || j < 0 || j >= g->Y || k < 0 || k >= g->Z) return 1;
+  return g->grid[grid_addr(g, i, j, k)] == 0 ? 0 : 1;
+}
+static void proj_in_map(const orc_grid *g, double p[3]) { /* PCSmap_manager.h:128-135 */
+  for (int d = 0; d < 3; ++d) {
+    if (p[d] < g->bmin[d]) p[d] = g->bmin[d];
+    if (p[d] > g->bmax[d]) p[d] = g->bmax[d];
+  }
+}
+static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
+
+size_t orc_map_points(const float *cloud, size_t n, double resolution, int sta_threshold,
+                      const double *centres, size_t m, const double halfbd[3], double *out_xyz,
+                      size_t cap, int dims_out[3]) {
+  orc_grid g;
+  g.res = resolution;
+  for (int d = 0; d < 3; ++d) { g.bmin[d] = 999999999; g.bmax[d] = -999999999; }
+  for (size_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) {
+      if (cloud[3 * i + d] > g.bmax[d]) g.bmax[d] = cloud[3 * i + d];
+      if (cloud[3 * i + d] < g.bmin[d]) g.bmin[d] = cloud[3 * i + d];
+    }
+  g.X = (int)ceil((g.bmax[0] - g.bmin[0]) / g.res); /* Gridmap3D.cpp:29-31 */
+  g.Y = (int)ceil((g.bmax[1] - g.bmin[1]) / g.res);
+  g.Z = (int)ceil((g.bmax[2] - g.bmin[2]) / g.res);
+  if (dims_out) { dims_out[0] = g.X; dims_out[1] = g.Y; dims_out[2] = g.Z; }
+  const size_t total = (size_t)g.X * g.Y * g.Z;
+  g.grid = (double *)calloc(total ? total : 1, sizeof(double));
+  for (size_t i = 0; i < n; ++i) {
+    double p[3] = {cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]};
+    int id[3];
+    grid_index(&g, p, id);
+    g.grid[grid_addr(&g, id[0], id[1], id[2])]++;
+  }
+  for (size_t a = 0; a < total; ++a) g.grid[a] = (g.grid[a] >= sta_threshold) ? 1 : 0;
+  /* plan_manager.cpp:156-167 */
+  int *ids = (int *)malloc(sizeof(int) * (total ? total : 1));
+  unsigned char *seen = (unsigned char *)calloc(total ? total : 1, 1);
+  size_t nid = 0;
+  double last[3] = {999, 999, 999};
+  for (size_t c = 0; c < m; ++c) {
+    double c1[3], c2[3], l1[3], l2[3];
+    for (int d = 0; d < 3; ++d) {
+      c1[d] = centres[3 * c + d] - halfbd[d]; c2[d] = centres[3 * c + d] + halfbd[d];
+      l1[d] = last[d] - halfbd[d]; l2[d] = last[d] + halfbd[d];
+    }
+    proj_in_map(&g, c1); proj_in_map(&g, c2); proj_in_map(&g, l1); proj_in_map(&g, l2);
+    int i1[3], i2[3], j1[3], j2[3];
+    grid_index(&g, c1, i1); grid_index(&g, c2, i2); grid_index(&g, l1, j1); grid_index(&g, l2, j2);
+    for (int i = i1[0]; i <= i2[0]; i++)
+      for (int j = i1[1]; j <= i2[1]; j++)
+        for (int k = i1[2]; k <= i2[2]; k++)
+          if (i > j2[0] || i < j1[0] || j > j2[1] || j < j1[1] || k > j2[2] || k < j1[2])
+            if (grid_occupied(&g, i, j, k)) {
+              const int uid = k * g.X * g.Y + j * g.X + i; /* unifiedID, PCSmap_manager.h:118-125 */
+              if (!seen[uid]) { seen[uid] = 1; ids[nid++] = uid; }
+            }
+    for (int d = 0; d < 3; ++d) last[d] = centres[3 * c + d];
+  }
+  qsort(ids, nid, sizeof(int), cmp_int);
+  for (size_t q = 0; q < nid && q < cap; ++q) {
+    const int uid = ids[q];
+    const int i = uid % g.X, j = (uid / g.X) % g.Y, k = uid / (g.X * g.Y);
+    out_xyz[3 * q + 0] = (i + 0.5) * g.res + g.bmin[0]; /* getGridCubeCenter, Gridmap3D.cpp:184-195 */
+    out_xyz[3 * q + 1] = (j + 0.5) * g.res + g.bmin[1];
+    out_xyz[3 * q + 2] = (k + 0.5) * g.res + g.bmin[2];
+  }
+  free(ids); free(seen); free(g.grid);
+  return nid;
+}

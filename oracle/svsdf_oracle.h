@@ -16,8 +16,9 @@
  * analytic anchors derivable from the cited formulas, (ii) the reference's own
  * shape meshes (src/plan_manager/shapes/<name>.obj, whose vertices must lie on/in the
  * zero level set of the matching SDF), (iii) an independently written pure-Python
- * second restatement (tests/golden/make_golden.py) and (iv) finite-difference
- * checks of the assembled gradient.  See DESIGN.md "Oracle".
+ * second restatement whose outputs are committed as golden vectors
+ * (tests/golden/make_golden.py -> tests/golden/golden_small.json) and (iv)
+ * finite-difference checks of the assembled gradient.  See DESIGN.md "Oracle".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library.  The product path (implicit-svsdf-planner_amd/csrc) never links,
@@ -142,6 +143,15 @@ void orc_minco_coeffs(const double head_state[9], const double tail_state[9], in
 void orc_forward_T(const double *tau, double *T, int N);   /* BEO:213-226 */
 void orc_backward_T(const double *T, double *tau, int N);  /* BEO:228-241 */
 int orc_smoothed_l1(double x, double mu, double *f, double *df); /* BEO:316-340 */
+
+/* ---- query-point producer ------------------------------------------- */
+/* PCSmapManager::rcvGlobalMapHandler (src/map_manager/src/PCSmap_manager.cpp:88-210) + the waypoint
+ * loop of plan_manager.cpp:156-175 over getPointsInAABBOutOfLastOne (PCSmap_manager.h:184-219).
+ * cloud: n x 3 float32; centres: m x 3; out_xyz capacity cap points; returns the number of points
+ * (sorted by unified voxel id; the reference's unordered_map order is unspecified). */
+size_t orc_map_points(const float *cloud, size_t n, double resolution, int sta_threshold,
+                      const double *centres, size_t m, const double halfbd[3],
+                      double *out_xyz, size_t cap, int dims_out[3]);
 
 #ifdef __cplusplus
 }
