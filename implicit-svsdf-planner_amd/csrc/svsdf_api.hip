@@ -19,6 +19,7 @@
 
 #include "../../include/svsdf_c.h"
 #include "svsdf_kernels.hpp"
+#include "svsdf_frontend.hpp"
 #include "svsdf_minco.hpp"
 #include "svsdf_points.hpp"
 
@@ -79,6 +80,13 @@ struct svsdf_ctx {
   int *d_nonfinite = nullptr;
   int h_nonfinite = 0;
   size_t e_end = 0;
+
+  // front-end batches (row f3): growing device scratch [father | child | pts | kt] + offsets + flags
+  double *d_fe = nullptr;
+  size_t fe_cap = 0;           // doubles
+  unsigned long long *d_fe_offs = nullptr;
+  int *d_fe_flag = nullptr;
+  size_t fe_edges_cap = 0;
 
   // profiling
   bool profile = false;  // per-launch HIP events (env SVSDF_PROFILE=1 or svsdf_set_profiling)
@@ -709,7 +717,7 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.phase,
                   ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
                   ctx->gs.sq_ub, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl, ctx->d_block_partials, ctx->d_sums,
-                  ctx->d_out, ctx->d_nonfinite};
+                  ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_offs, ctx->d_fe_flag};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_in) (void)hipHostFree(ctx->h_in);
@@ -816,6 +824,124 @@ int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out) {
   if (!ctx || !out) return SVSDF_ERR_INVALID;
   *out = ctx->stats;
+  return SVSDF_OK;
+}
+
+// ---- front end -----------------------------------------------------------------
+int svsdf_check_sub_sw_collision(svsdf_ctx *ctx, size_t n_edges, const double *father_states,
+                                 const double *child_states, const size_t *pts_offset, const double *pts_xy,
+                                 unsigned char *free_out) {
+  if (!ctx || ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "svsdf_check_sub_sw_collision: no device context");
+  if (n_edges == 0) return SVSDF_OK;
+  if (!father_states || !child_states || !pts_offset || !free_out)
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_check_sub_sw_collision: null argument");
+  const size_t total = pts_offset[n_edges];
+  if (pts_offset[0] != 0 || (total && !pts_xy))
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_check_sub_sw_collision: bad offsets");
+  size_t max_pts = 0;
+  for (size_t e = 0; e < n_edges; ++e) {
+    if (pts_offset[e + 1] < pts_offset[e]) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_check_sub_sw_collision: offsets not monotone");
+    max_pts = std::max(max_pts, pts_offset[e + 1] - pts_offset[e]);
+  }
+  if (n_edges > 0x7fffffffu || (max_pts + kSubswPoints - 1) / kSubswPoints > 65535u)
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_check_sub_sw_collision: batch too large");
+  // kt = 0, 0.02, ... by accumulated adds while kt <= 1.0 (SWM:1189)
+  double kt_tab[kMaxKt];
+  int nkt = 0;
+  for (double kt = 0.0; kt <= 1.0 && nkt < kMaxKt; kt += 0.02) kt_tab[nkt++] = kt;
+  if (total == 0) { std::memset(free_out, 1, n_edges); return SVSDF_OK; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t need = 6 * n_edges + 2 * total + kMaxKt;
+  if (need > ctx->fe_cap) {
+    int rc = dev_alloc(ctx, &ctx->d_fe, need + need / 2);
+    if (rc) return rc;
+    ctx->fe_cap = need + need / 2;
+  }
+  if (n_edges + 1 > ctx->fe_edges_cap) {
+    int rc = dev_alloc(ctx, &ctx->d_fe_offs, 2 * n_edges + 1);
+    if (rc) return rc;
+    rc = dev_alloc(ctx, &ctx->d_fe_flag, 2 * n_edges + 1);
+    if (rc) return rc;
+    ctx->fe_edges_cap = 2 * n_edges + 1;
+  }
+  double *d_father = ctx->d_fe, *d_child = d_father + 3 * n_edges, *d_pts = d_child + 3 * n_edges;
+  double *d_kt = d_pts + 2 * total;
+  std::vector<unsigned long long> offs(n_edges + 1);
+  for (size_t e = 0; e <= n_edges; ++e) offs[e] = pts_offset[e];
+  std::vector<int> flags(n_edges, 1);
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(d_father, father_states, 3 * n_edges * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_child, child_states, 3 * n_edges * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_pts, pts_xy, 2 * total * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_kt, kt_tab, nkt * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->d_fe_offs, offs.data(), (n_edges + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->d_fe_flag, flags.data(), n_edges * sizeof(int), hipMemcpyHostToDevice, st));
+  const dim3 grid((unsigned)n_edges, (unsigned)((max_pts + kSubswPoints - 1) / kSubswPoints));
+#define CALL(S)                                                                                              \
+  hipLaunchKernelGGL((k_subsw<S>), grid, dim3(kSubswBlock), 0, st, ctx->sp, d_father, d_child, ctx->d_fe_offs, \
+                     d_pts, d_kt, nkt, ctx->d_fe_flag)
+  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_fe_flag, n_edges * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (size_t e = 0; e < n_edges; ++e) free_out[e] = flags[e] ? 1 : 0;
+  return SVSDF_OK;
+}
+
+int svsdf_shape_kernels(svsdf_ctx *ctx, int kernel_size, int kernel_count, double kernel_resolution,
+                        double safemargin, unsigned char *map_out, unsigned char *bytes_out, double *yaw_out,
+                        int *loop_count) {
+  if (!ctx || ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "svsdf_shape_kernels: no device context");
+  if (kernel_size <= 0 || kernel_count <= 0 || kernel_size > 4096 || kernel_count > 65536 || !map_out)
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_shape_kernels: bad argument");
+  if (ctx->cfg.shape_id == SVSDF_SHAPE_Polygon)
+    return fail(ctx, SVSDF_ERR_INVALID,
+                "svsdf_shape_kernels: Polygon has no getonlySDF(pos_rel, Matrix3d) in the reference (Shape.hpp:1477)");
+  // yaw table: for (yaw = -PI; yaw < PI; yaw += yaw_res) (SHP:400-401); PI macro of SHP:31
+  const double PI_ = 3.14159265358979323846;
+  const double yaw_res = 2 * PI_ / kernel_count;
+  std::vector<double> yaws;
+  int ind = 0;
+  for (double yaw = -PI_; yaw < PI_; yaw += yaw_res, ind++)
+    if (ind < kernel_count) yaws.push_back(yaw);
+  if (loop_count) *loop_count = ind;
+  const int count = (int)yaws.size();
+  const int size_side = (int)(0.5 * (kernel_size - 1));
+  const size_t cells = (size_t)kernel_size * kernel_size;
+  HIPCHK(hipSetDevice(ctx->device));
+  double *d_yaw = nullptr;
+  unsigned char *d_map = nullptr;
+  HIPCHK(hipMalloc((void **)&d_yaw, count * sizeof(double)));
+  if (hipMalloc((void **)&d_map, cells * count) != hipSuccess) {
+    (void)hipFree(d_yaw);
+    return fail(ctx, SVSDF_ERR_HIP_BASE + (int)hipErrorOutOfMemory, "svsdf_shape_kernels: hipMalloc");
+  }
+  hipStream_t st = ctx->stream;
+  hipError_t e1 = hipMemcpyAsync(d_yaw, yaws.data(), count * sizeof(double), hipMemcpyHostToDevice, st);
+  const unsigned grid = (unsigned)((cells * count + kBlock - 1) / kBlock);
+#define CALL(S)                                                                                             \
+  hipLaunchKernelGGL((k_shape_kernels<S>), dim3(grid), dim3(kBlock), 0, st, ctx->sp, kernel_size, count,    \
+                     kernel_resolution, size_side, safemargin, d_yaw, d_map)
+  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
+#undef CALL
+  hipError_t e2 = hipGetLastError();
+  hipError_t e3 = hipMemcpyAsync(map_out, d_map, cells * count, hipMemcpyDeviceToHost, st);
+  hipError_t e4 = hipStreamSynchronize(st);
+  (void)hipFree(d_yaw);
+  (void)hipFree(d_map);
+  for (hipError_t e : {e1, e2, e3, e4})
+    if (e != hipSuccess) return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e, std::string("svsdf_shape_kernels: ") + hipGetErrorString(e));
+  if (yaw_out) std::memcpy(yaw_out, yaws.data(), count * sizeof(double));
+  if (bytes_out) {  // byteShapeKernel::generateByteKernel SHP:194-216, or_mask SHP:95
+    const int bpl = (kernel_size + 7) / 8;
+    std::memset(bytes_out, 0, (size_t)count * kernel_size * bpl);
+    for (int k = 0; k < count; ++k)
+      for (int a = 0; a < kernel_size; ++a)
+        for (int b = 0; b < kernel_size; ++b)
+          if (map_out[(size_t)k * cells + (size_t)a * kernel_size + b])
+            bytes_out[((size_t)k * kernel_size + a) * bpl + b / 8] |= (unsigned char)(0x80u >> (b % 8));
+  }
   return SVSDF_OK;
 }
 

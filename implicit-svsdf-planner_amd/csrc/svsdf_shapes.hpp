@@ -267,6 +267,26 @@ __device__ inline double sdf_polygon(const ShapeParams &sp, double x, double y, 
   return (rs % 2 == 0) ? dis_min : -dis_min;
 }
 
+// The shape formula proper, on the shape-local point (after trans / Rotate).
+template <int SHAPE>
+__device__ __forceinline__ double shape_core(const ShapeParams &sp, double px, double py) {
+  if constexpr (SHAPE == kUnevenCapsule) return sdf_uneven_capsule(px, py);
+  else if constexpr (SHAPE == kCutDisk) return sdf_cut_disk(px, py);
+  else if constexpr (SHAPE == kTrapezoid) return sdf_trapezoid(px, py);
+  else if constexpr (SHAPE == kRhombus) return sdf_rhombus(px, py);
+  else if constexpr (SHAPE == kStar) return sdf_star(px, py);
+  else if constexpr (SHAPE == kTunnel) return sdf_tunnel(px, py);
+  else if constexpr (SHAPE == kHorseshoe) return sdf_horseshoe(px, py, sp.c0x, sp.c0y);
+  else if constexpr (SHAPE == kHeart) return sdf_heart(px, py);
+  else if constexpr (SHAPE == kOrientedVesica) return sdf_oriented_vesica(px, py);
+  else if constexpr (SHAPE == kRoundedCross) return sdf_rounded_cross(px, py);
+  else if constexpr (SHAPE == kRoundedX) return sdf_rounded_x(px, py, 3.0);
+  else if constexpr (SHAPE == kBigX) return sdf_rounded_x(px, py, 5.0);
+  else if constexpr (SHAPE == kMoon) return sdf_moon(px, py);
+  else if constexpr (SHAPE == kPie || SHAPE == kPie2) return sdf_pie(px, py, sp.c0x, sp.c0y);
+  else return sdf_arc(px, py, sp.c0x, sp.c0y);
+}
+
 // getonlySDF(pos_rel): ((pos_rel - trans) * Rotate).head(2) then the shape formula.
 template <int SHAPE>
 __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, double y) {
@@ -279,22 +299,22 @@ __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, dou
       px = dx * sp.r00 + dy * sp.r10;
       py = dx * sp.r01 + dy * sp.r11;
     }
-    if constexpr (SHAPE == kUnevenCapsule) return sdf_uneven_capsule(px, py);
-    else if constexpr (SHAPE == kCutDisk) return sdf_cut_disk(px, py);
-    else if constexpr (SHAPE == kTrapezoid) return sdf_trapezoid(px, py);
-    else if constexpr (SHAPE == kRhombus) return sdf_rhombus(px, py);
-    else if constexpr (SHAPE == kStar) return sdf_star(px, py);
-    else if constexpr (SHAPE == kTunnel) return sdf_tunnel(px, py);
-    else if constexpr (SHAPE == kHorseshoe) return sdf_horseshoe(px, py, sp.c0x, sp.c0y);
-    else if constexpr (SHAPE == kHeart) return sdf_heart(px, py);
-    else if constexpr (SHAPE == kOrientedVesica) return sdf_oriented_vesica(px, py);
-    else if constexpr (SHAPE == kRoundedCross) return sdf_rounded_cross(px, py);
-    else if constexpr (SHAPE == kRoundedX) return sdf_rounded_x(px, py, 3.0);
-    else if constexpr (SHAPE == kBigX) return sdf_rounded_x(px, py, 5.0);
-    else if constexpr (SHAPE == kMoon) return sdf_moon(px, py);
-    else if constexpr (SHAPE == kPie || SHAPE == kPie2) return sdf_pie(px, py, sp.c0x, sp.c0y);
-    else return sdf_arc(px, py, sp.c0x, sp.c0y);
+    return shape_core<SHAPE>(sp, px, py);
   }
+}
+
+// getonlySDF(pos_rel, R_obj) (2-argument overloads, e.g. SHP:545-559): ((pos_rel - trans) * Rotate *
+// R_obj).head(2) with R_obj = AngleAxisd(yaw, Z), i.e. the row vector times [[c,-s],[s,c]].  Not defined
+// for Polygon in the reference (SHP:1477 does not override the Matrix3d virtual).
+template <int SHAPE>
+__device__ __forceinline__ double shape_sdf_rot(const ShapeParams &sp, double x, double y, double c, double s) {
+  static_assert(SHAPE != kPolygon, "Polygon has no (pos_rel, R_obj) overload");
+  const double dx = x - sp.tx, dy = y - sp.ty;
+  const double qx = dx * sp.r00 + dy * sp.r10;
+  const double qy = dx * sp.r01 + dy * sp.r11;
+  const double px = qx * c + qy * s;
+  const double py = qx * (-s) + qy * c;
+  return shape_core<SHAPE>(sp, px, py);
 }
 
 // getonlyGrad1: central FD, dx = 1e-6 (SHP:35-53); Polygon: analytic (SHP:1505-1531).

@@ -24,6 +24,7 @@ EXPORTS = [
     "svsdf_query_points", "svsdf_last_stats", "svsdf_shard_indices", "svsdf_set_profiling",
     "svsdf_shard_plan", "svsdf_lmbm_prepare", "svsdf_debug_sincos_mismatches",
     "svsdf_map_create", "svsdf_map_destroy", "svsdf_map_info", "svsdf_map_gather", "svsdf_pcd_read_ascii",
+    "svsdf_check_sub_sw_collision", "svsdf_shape_kernels",
 ]
 
 
@@ -105,6 +106,10 @@ def lib():
     L.svsdf_pcd_read_ascii.argtypes = [C.c_char_p, _fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.svsdf_debug_sincos_mismatches.restype = C.c_longlong
     L.svsdf_debug_sincos_mismatches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+    _u8p = C.POINTER(C.c_ubyte)
+    L.svsdf_check_sub_sw_collision.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, C.POINTER(C.c_size_t), _dp, _u8p]
+    L.svsdf_shape_kernels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p, _dp,
+                                      C.POINTER(C.c_int)]
     _LIB = L
     return L
 
@@ -356,6 +361,42 @@ class SvsdfContext:
         idx = self.shard_indices()
         order = np.argsort(idx, kind="stable")
         return sdf[order], ts[order], g[order], idx[order]
+
+    # ---- front end ----
+    def check_sub_sw_collision(self, father_states, child_states, points_per_edge):
+        """Batched SweptVolumeManager::checkSubSWCollision (sw_manager.hpp:1171-1211).
+
+        father_states / child_states: (E, 3) arrays of (x, y, yaw); points_per_edge: sequence of E
+        (n_e, 2) obstacle-point arrays.  Returns a bool array, True where the reference returns true."""
+        fs = _f64(father_states).reshape(-1, 3)
+        cs = _f64(child_states).reshape(-1, 3)
+        E = len(fs)
+        if len(cs) != E or len(points_per_edge) != E:
+            raise ValueError("check_sub_sw_collision: one child state and one point set per edge")
+        pts = [_f64(q).reshape(-1, 2) for q in points_per_edge]
+        offs = np.zeros(E + 1, dtype=np.uintp)
+        if E:
+            offs[1:] = np.cumsum([len(q) for q in pts])
+        flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if E and offs[-1] else np.zeros((0, 2))
+        out = np.zeros(max(E, 1), dtype=np.uint8)
+        self._chk(self.L.svsdf_check_sub_sw_collision(
+            self.ctx, E, _p(fs), _p(cs), offs.ctypes.data_as(C.POINTER(C.c_size_t)), _p(flat),
+            out.ctypes.data_as(C.POINTER(C.c_ubyte))), "svsdf_check_sub_sw_collision")
+        return out[:E].astype(bool)
+
+    def shape_kernels(self, kernel_size, kernel_count, resolution, safemargin):
+        """BasicShape::initShape (Shape.hpp:386-430): returns (map (K, ks, ks) bool, bytes (K, ks, (ks+7)//8)
+        uint8, yaws (K,), loop_count)."""
+        ks, K = int(kernel_size), int(kernel_count)
+        m = np.zeros((K, ks, ks), dtype=np.uint8)
+        b = np.zeros((K, ks, (ks + 7) // 8), dtype=np.uint8)
+        yaws = np.zeros(K)
+        n = C.c_int(0)
+        u8 = C.POINTER(C.c_ubyte)
+        self._chk(self.L.svsdf_shape_kernels(self.ctx, ks, K, float(resolution), float(safemargin),
+                                             m.ctypes.data_as(u8), b.ctypes.data_as(u8), _p(yaws), C.byref(n)),
+                  "svsdf_shape_kernels")
+        return m.astype(bool), b, yaws, n.value
 
     def sincos_mismatches(self, lo, hi, n):
         return int(self.L.svsdf_debug_sincos_mismatches(self.ctx, float(lo), float(hi), int(n)))

@@ -149,6 +149,31 @@ int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial,
 int svsdf_lmbm_prepare(svsdf_ctx *ctx, const double *x, int n, double *coeffs_out, double *T_out);
 double svsdf_lmbm_finish(svsdf_ctx *ctx, const double *partial_host, double *g, int n);
 
+/* ---- front-end consumers of the same shape SDFs (device) ------------------------- */
+/* Replaces SweptVolumeManager::checkSubSWCollision (src/swept_volume/include/swept_volume/sw_manager.hpp:
+ * 1171-1211), batched: the reference calls it once per A* edge from AstarPathSearcher::AstarGetSucc
+ * (src/planner_algorithm/include/planner_algorithm/front_end_Astar.hpp:192-241) with the obstacle points of
+ * getPointsInAABB2D around the child cell.  Edge e: father_states[3e..] / child_states[3e..] = (x, y, yaw),
+ * obstacle points pts_xy[2*pts_offset[e] .. 2*pts_offset[e+1]) (pts_offset has n_edges+1 entries,
+ * pts_offset[0] == 0).  free_out[e] = 1 where the reference returns true (no interpolated pose kt = 0,
+ * 0.02, ..., <= 1 has sdf < 0 at any point), else 0.  Needs no trajectory and no svsdf_set_points. */
+int svsdf_check_sub_sw_collision(svsdf_ctx *ctx, size_t n_edges, const double *father_states,
+                                 const double *child_states, const size_t *pts_offset, const double *pts_xy,
+                                 unsigned char *free_out);
+/* Replaces BasicShape::initShape (src/utils/include/utils/Shape.hpp:386-430) + byteShapeKernel::
+ * generateByteKernel (:194-216): per yaw index k (yaw_k from the reference's accumulated loop
+ * `for (yaw = -PI; yaw < PI; yaw += 2*PI/kernel_count)`), cell (a, b) of the kernel_size^2 grid is occupied iff
+ * getonlySDF((resu*a - side*resu, resu*b - side*resu), R(yaw_k)) <= safemargin
+ * (safemargin = max(front_end_safeh, occupancy_resolution/2) at Shape.hpp:399).
+ * map_out: kernel_count * kernel_size^2 bools [k][a][b]; bytes_out (may be NULL): kernel_count * kernel_size *
+ * ((kernel_size+7)/8) bytes, bit (0x80 >> b%8) of byte [k][a][b/8]; yaw_out (may be NULL): kernel_count yaws;
+ * loop_count (may be NULL): iterations the reference loop makes (kernel_count, or kernel_count+1 when
+ * rounding lets the last yaw stay below PI -- the reference then writes past its arrays; only kernel_count
+ * kernels are produced here).  Polygon -> SVSDF_ERR_INVALID (no such overload in the reference). */
+int svsdf_shape_kernels(svsdf_ctx *ctx, int kernel_size, int kernel_count, double kernel_resolution,
+                        double safemargin, unsigned char *map_out, unsigned char *bytes_out, double *yaw_out,
+                        int *loop_count);
+
 /* ---- query-point producer (host) ------------------------------------------------ */
 /* Replaces, for the data this path consumes, PCSmapManager::rcvGlobalMapHandler
  * (src/map_manager/src/PCSmap_manager.cpp:88-210: cloud -> bounds -> occupancy grid with

@@ -71,6 +71,11 @@ def lib():
     L.orc_map_points.restype = C.c_size_t
     L.orc_map_points.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp,
                                  C.c_size_t, C.POINTER(C.c_int)]
+    _u8p = C.POINTER(C.c_ubyte)
+    L.orc_check_sub_sw_collision.restype = C.c_int
+    L.orc_check_sub_sw_collision.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_size_t]
+    L.orc_shape_kernels.restype = C.c_int
+    L.orc_shape_kernels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p, _dp]
     _LIB = L
     return L
 
@@ -166,6 +171,22 @@ class Oracle:
         if per_point:
             return cost.value, gT, gC2, sdf, ts, pc
         return cost.value, gT, gC2
+
+    # ---- SURVEY.md §8 row f3 ----
+    def check_sub_sw_collision(self, father, child, pts_xy):
+        f, c = _f64(father).reshape(3), _f64(child).reshape(3)
+        q = _f64(pts_xy).reshape(-1, 2)
+        return bool(self.L.orc_check_sub_sw_collision(self.ctx, _p(f), _p(c), _p(q), len(q)))
+
+    def shape_kernels(self, kernel_size, kernel_count, resolution, safemargin):
+        ks, K = int(kernel_size), int(kernel_count)
+        m = np.zeros((K, ks, ks), dtype=np.uint8)
+        b = np.zeros((K, ks, (ks + 7) // 8), dtype=np.uint8)
+        yaws = np.zeros(K)
+        u8 = C.POINTER(C.c_ubyte)
+        n = self.L.orc_shape_kernels(self.ctx, ks, K, float(resolution), float(safemargin),
+                                     m.ctypes.data_as(u8), b.ctypes.data_as(u8), _p(yaws))
+        return m.astype(bool), b, yaws, n
 
     def counters(self):
         c = Counters()

@@ -345,6 +345,40 @@ double orc_shape_sdf(const orc_shape *s, double x, double y) {
   }
 }
 
+/* getonlySDF(pos_rel, R_obj) (the 2-argument overloads, e.g. SHP:545-559, 603-616): identical bodies
+ * to the 1-argument forms after Pos_rel = ((pos_rel - trans) * Rotate * R_obj).head(2), with
+ * R_obj = AngleAxisd(yaw, Z) = [[c,-s,0],[s,c,0],[0,0,1]] -> row vector times R_obj.
+ * Polygon has no override with this signature (SHP:1477 takes a Matrix2d), so the reference's
+ * virtual call lands in the empty base body (SHP:267): not defined, returns NaN here. */
+double orc_shape_sdf_rot(const orc_shape *s, double x, double y, double yaw) {
+  if (s->id == ORC_SHAPE_Polygon) return NAN;
+  double qx, qy;
+  shape_local(s, x, y, &qx, &qy);
+  double c = cos(yaw), sn = sin(yaw);
+  double px = qx * c + qy * sn;
+  double py = qx * (-sn) + qy * c;
+  tl_cnt.shape_evals++;
+  switch (s->id) {
+    case ORC_SHAPE_sdUnevenCapsule: return sdf_uneven_capsule(px, py);
+    case ORC_SHAPE_sdCutDisk: return sdf_cut_disk(px, py);
+    case ORC_SHAPE_sdTrapezoid: return sdf_trapezoid(px, py);
+    case ORC_SHAPE_sdRhombus: return sdf_rhombus(px, py);
+    case ORC_SHAPE_star: return sdf_star(px, py);
+    case ORC_SHAPE_sdTunnel: return sdf_tunnel(px, py);
+    case ORC_SHAPE_sdHorseshoe: return sdf_horseshoe(s, px, py);
+    case ORC_SHAPE_sdHeart: return sdf_heart(px, py);
+    case ORC_SHAPE_sdOrientedVesica: return sdf_oriented_vesica(px, py);
+    case ORC_SHAPE_sdRoundedCross: return sdf_rounded_cross(px, py);
+    case ORC_SHAPE_sdRoundedX: return sdf_rounded_x(px, py, 3.0);
+    case ORC_SHAPE_bigX: return sdf_rounded_x(px, py, 5.0);
+    case ORC_SHAPE_sdMoon: return sdf_moon(px, py);
+    case ORC_SHAPE_sdPie: return sdf_pie(px, py, s->pie_cx, s->pie_cy);
+    case ORC_SHAPE_sdPie2: return sdf_pie(px, py, s->pie2_cx, s->pie2_cy);
+    case ORC_SHAPE_sdArc: return sdf_arc(s, px, py);
+    default: return 1e9;
+  }
+}
+
 /* getonlyGrad1: FD macro SHP:35-53 for the analytic shapes, analytic for Polygon SHP:1505-1531 */
 void orc_shape_grad(const orc_shape *s, double x, double y, double g[2]) {
   if (s->id == ORC_SHAPE_Polygon) {
@@ -1257,4 +1291,64 @@ size_t orc_map_points(const float *cloud, size_t n, double resolution, int sta_t
   }
   free(ids); free(seen); free(g.grid);
   return nid;
+}
+
+/* ------------------------------------------------------------------------- */
+/* front-end continuous collision check + shape kernels  */
+/* ------------------------------------------------------------------------- */
+/* SweptVolumeManager::checkSubSWCollision SWM:1171-1211: for every obstacle point scan the
+ * linearly interpolated pose kt = 0, 0.02, ... (accumulated adds, kt <= 1.0) and fail on the
+ * first negative SDF.  Returns 1 (= reference `true`, edge is free) or 0. */
+int orc_check_sub_sw_collision(orc_ctx *ctx, const double father[3], const double child[3],
+                               const double *pts_xy, size_t n) {
+  const double dt = 0.02;
+  for (size_t i = 0; i < n; ++i) {
+    double min_sdf = 1e9, temp_sdf = 1e8;
+    for (double kt = 0.0; kt <= 1.0; kt += dt) {
+      double lx = kt * child[0] + (1 - kt) * father[0];
+      double ly = kt * child[1] + (1 - kt) * father[1];
+      double yaw = kt * child[2] + (1 - kt) * father[2];
+      double s = sin(yaw), c = cos(yaw);
+      double dx = pts_xy[2 * i] - lx, dy = pts_xy[2 * i + 1] - ly;
+      double rx = c * dx + s * dy;
+      double ry = (-s) * dx + c * dy;
+      temp_sdf = orc_shape_sdf(&ctx->shape, rx, ry);
+      if (temp_sdf < min_sdf) min_sdf = temp_sdf;
+      if (min_sdf < 0) return 0;
+    }
+  }
+  return 1;
+}
+
+/* BasicShape::initShape SHP:386-430 + byteShapeKernel::generateByteKernel SHP:194-216.
+ * map_out: kernel_count x ks x ks bools (a-major: map[a*ks+b]); bytes_out: kernel_count x
+ * ks*((ks+7)/8) bytes, bit b of row a = or_mask[b%8] (0x80 >> (b%8)) of byte a*bpl + b/8;
+ * yaw_out: kernel_count yaws of the accumulated loop `for (yaw=-PI; yaw<PI; yaw+=yaw_res)`.
+ * Returns the number of kernels the reference loop would produce (it can exceed kernel_count by
+ * one through rounding, which overflows the reference's arrays; only kernel_count are written). */
+int orc_shape_kernels(orc_ctx *ctx, int ks, int kernel_count, double resu, double safemargin,
+                      unsigned char *map_out, unsigned char *bytes_out, double *yaw_out) {
+  static const unsigned char or_mask[8] = {0x80, 0x40, 0x20, 0x10, 0x08, 0x04, 0x02, 0x01}; /* SHP:95 */
+  const double PI_ = 3.14159265358979323846; /* SHP:31 */
+  int size_side = (int)(0.5 * (ks - 1));
+  int bpl = (ks + 7) / 8;
+  double yaw_res = 2 * PI_ / kernel_count;
+  int ind = 0;
+  for (double yaw = -PI_; yaw < PI_; yaw += yaw_res, ind++) {
+    if (ind >= kernel_count) continue;
+    if (yaw_out) yaw_out[ind] = yaw;
+    unsigned char *m = map_out + (size_t)ind * ks * ks;
+    unsigned char *bm = bytes_out ? bytes_out + (size_t)ind * ks * bpl : NULL;
+    if (bm) memset(bm, 0, (size_t)ks * bpl);
+    for (int a = 0; a < ks; ++a)
+      for (int b = 0; b < ks; ++b) {
+        double x = resu * a - size_side * resu;
+        double y = resu * b - size_side * resu;
+        double sdf = orc_shape_sdf_rot(&ctx->shape, x, y, yaw);
+        unsigned char occ = (sdf <= safemargin) ? 1 : 0;
+        m[a * ks + b] = occ;
+        if (bm && occ) bm[a * bpl + b / 8] |= or_mask[b % 8];
+      }
+  }
+  return ind;
 }

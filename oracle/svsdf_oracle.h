@@ -153,6 +153,16 @@ size_t orc_map_points(const float *cloud, size_t n, double resolution, int sta_t
                       const double *centres, size_t m, const double halfbd[3],
                       double *out_xyz, size_t cap, int dims_out[3]);
 
+/* ---- front-end collision check + shape kernels ------------------------ */
+/* getonlySDF(pos_rel, R_obj) with R_obj = AngleAxisd(yaw, Z) (2-argument overloads, SHP:545-559 ...). */
+double orc_shape_sdf_rot(const orc_shape *s, double x, double y, double yaw);
+/* checkSubSWCollision SWM:1171-1211: 1 = edge free (reference returns true), 0 = collision. */
+int orc_check_sub_sw_collision(orc_ctx *ctx, const double father[3], const double child[3],
+                               const double *pts_xy, size_t n);
+/* initShape SHP:386-430 + generateByteKernel SHP:194-216; returns the reference loop's kernel count. */
+int orc_shape_kernels(orc_ctx *ctx, int ks, int kernel_count, double resu, double safemargin,
+                      unsigned char *map_out, unsigned char *bytes_out, double *yaw_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ Run:  python tests/golden/make_golden.py      (about a minute; pure-Python loops
 """
 import json
 import math
+import sys
 import os
 
 PI = 3.14159265358979323846  # SHP:31
@@ -569,6 +570,86 @@ def main():
                    cases=cases), open(out, "w"))
     print("wrote", out, os.path.getsize(out), "bytes")
 
+# ---- front-end collision check + shape kernels ---------------------------------------
+def check_sub_sw_collision(shape, father, child, pts):  # SWM:1171-1211
+    dt = 0.02
+    for (px, py) in pts:
+        min_sdf = 1e9
+        kt = 0.0
+        while kt <= 1.0:
+            lx = kt * child[0] + (1 - kt) * father[0]
+            ly = kt * child[1] + (1 - kt) * father[1]
+            yaw = kt * child[2] + (1 - kt) * father[2]
+            s, c = math.sin(yaw), math.cos(yaw)
+            dx, dy = px - lx, py - ly
+            temp = shape.sdf(c * dx + s * dy, (-s) * dx + c * dy)  # posEva2Rel SWM:521-526
+            if temp < min_sdf:
+                min_sdf = temp
+            if min_sdf < 0:
+                return False
+            kt += dt
+    return True
+
+
+def shape_kernels(shape, ks, count, resu, safemargin):  # SHP:386-430 with the (pos_rel, R_obj) overloads
+    size_side = int(0.5 * (ks - 1))
+    yaw_res = 2 * PI / count
+    maps, yaws = [], []
+    yaw, ind = -PI, 0
+    while yaw < PI:
+        if ind < count:
+            c, s = math.cos(yaw), math.sin(yaw)
+            rows = []
+            for a in range(ks):
+                row = []
+                for b in range(ks):
+                    x = resu * a - size_side * resu
+                    y = resu * b - size_side * resu
+                    qx, qy = shape.local(x, y)
+                    px, py = qx * c + qy * s, qx * (-s) + qy * c  # row vector times R_obj = AngleAxisd(yaw, Z)
+                    row.append(1 if getattr(shape, "f_" + shape.name)(px, py) <= safemargin else 0)
+                rows.append(row)
+            maps.append(rows)
+            yaws.append(yaw)
+        yaw += yaw_res
+        ind += 1
+    return maps, yaws, ind
+
+
+def main_frontend():
+    import random
+    rng = random.Random(20240807)
+    cases = []
+    shapes = {"star": (0.0, 0.0, 0.0), "sdHorseshoe": (0.0, 0.0, 0.0), "sdHeart": (0.0, 0.0, 0.0),
+              "sdCutDisk": (0.0, -3.0, 0.0), "Polygon": (0.0, 0.0, 0.0)}
+    for name, pp in shapes.items():
+        verts = [(6, -0.1), (6, 0.1), (-6, 0.1), (-6, -0.1)] if name == "Polygon" else None
+        sh = Shape(name, pp, verts)
+        edges = []
+        for _ in range(24):
+            fx, fy = rng.uniform(5, 25), rng.uniform(5, 25)
+            father = [fx, fy, rng.uniform(-PI, PI)]
+            child = [fx + rng.choice([-1.0, 0.0, 1.0]), fy + rng.choice([-1.0, 0.0, 1.0]),
+                     father[2] + rng.uniform(-0.7, 0.7)]
+            n = rng.randrange(1, 6)
+            pts = [[fx + rng.uniform(-6, 6), fy + rng.uniform(-6, 6)] for _ in range(n)]
+            edges.append(dict(father=father, child=child, points=pts,
+                              free=check_sub_sw_collision(sh, father, child, pts)))
+        case = dict(shape=name, poly_params=list(pp), polygon=verts, edges=edges)
+        if name != "Polygon":
+            maps, yaws, ind = shape_kernels(sh, 17, 18, 1.0, 0.5)
+            case.update(kernel_size=17, kernel_count=18, resolution=1.0, safemargin=0.5, kernels=maps, yaws=yaws,
+                        loop_count=ind)
+        print(name, "free edges", sum(e["free"] for e in edges), "/", len(edges))
+        cases.append(case)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_frontend.json")
+    json.dump(dict(generator="tests/golden/make_golden.py main_frontend() (pure-Python restatement of "
+                             "checkSubSWCollision SWM:1171-1211 and initShape SHP:386-430)", cases=cases),
+              open(out, "w"))
+    print("wrote", out, os.path.getsize(out), "bytes")
+
 
 if __name__ == "__main__":
-    main()
+    if "--frontend-only" not in sys.argv:
+        main()
+    main_frontend()
