@@ -82,10 +82,10 @@ struct svsdf_ctx {
   size_t e_end = 0;
 
   // front-end batches (row f3): growing device scratch [father | child | pts | kt] + offsets + flags
-  double *d_fe = nullptr;
-  size_t fe_cap = 0;           // doubles
-  unsigned long long *d_fe_offs = nullptr;
+  double *d_fe = nullptr, *h_fe = nullptr;   // device buffer + pinned staging mirror
+  size_t fe_cap = 0;                          // doubles
   int *d_fe_flag = nullptr;
+  std::vector<int> h_fe_flag;
   size_t fe_edges_cap = 0;
 
   // profiling
@@ -717,11 +717,12 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.phase,
                   ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
                   ctx->gs.sq_ub, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl, ctx->d_block_partials, ctx->d_sums,
-                  ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_offs, ctx->d_fe_flag};
+                  ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_flag};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_in) (void)hipHostFree(ctx->h_in);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+  if (ctx->h_fe) (void)hipHostFree(ctx->h_fe);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   for (int b = 0; b < kMaxBatches; ++b) {
@@ -851,41 +852,45 @@ int svsdf_check_sub_sw_collision(svsdf_ctx *ctx, size_t n_edges, const double *f
   for (double kt = 0.0; kt <= 1.0 && nkt < kMaxKt; kt += 0.02) kt_tab[nkt++] = kt;
   if (total == 0) { std::memset(free_out, 1, n_edges); return SVSDF_OK; }
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t need = 6 * n_edges + 2 * total + kMaxKt;
+  // one packed upload: [father 3E | child 3E | kt 64 | offsets E+1 (u64) | pts 2T] through a pinned staging buffer
+  const size_t need = 6 * n_edges + kMaxKt + (n_edges + 1) + 2 * total;
   if (need > ctx->fe_cap) {
-    int rc = dev_alloc(ctx, &ctx->d_fe, need + need / 2);
+    const size_t cap = need + need / 2;
+    int rc = dev_alloc(ctx, &ctx->d_fe, cap);
     if (rc) return rc;
-    ctx->fe_cap = need + need / 2;
+    if (ctx->h_fe) { (void)hipHostFree(ctx->h_fe); ctx->h_fe = nullptr; }
+    HIPCHK(hipHostMalloc((void **)&ctx->h_fe, cap * sizeof(double)));
+    ctx->fe_cap = cap;
   }
-  if (n_edges + 1 > ctx->fe_edges_cap) {
-    int rc = dev_alloc(ctx, &ctx->d_fe_offs, 2 * n_edges + 1);
+  if (n_edges > ctx->fe_edges_cap) {
+    int rc = dev_alloc(ctx, &ctx->d_fe_flag, 2 * n_edges);
     if (rc) return rc;
-    rc = dev_alloc(ctx, &ctx->d_fe_flag, 2 * n_edges + 1);
-    if (rc) return rc;
-    ctx->fe_edges_cap = 2 * n_edges + 1;
+    ctx->fe_edges_cap = 2 * n_edges;
+    ctx->h_fe_flag.resize(2 * n_edges);
   }
-  double *d_father = ctx->d_fe, *d_child = d_father + 3 * n_edges, *d_pts = d_child + 3 * n_edges;
-  double *d_kt = d_pts + 2 * total;
-  std::vector<unsigned long long> offs(n_edges + 1);
-  for (size_t e = 0; e <= n_edges; ++e) offs[e] = pts_offset[e];
-  std::vector<int> flags(n_edges, 1);
+  double *h = ctx->h_fe;
+  std::memcpy(h, father_states, 3 * n_edges * sizeof(double));
+  std::memcpy(h + 3 * n_edges, child_states, 3 * n_edges * sizeof(double));
+  std::memcpy(h + 6 * n_edges, kt_tab, kMaxKt * sizeof(double));
+  unsigned long long *h_offs = reinterpret_cast<unsigned long long *>(h + 6 * n_edges + kMaxKt);
+  for (size_t e = 0; e <= n_edges; ++e) h_offs[e] = pts_offset[e];
+  std::memcpy(h + 6 * n_edges + kMaxKt + n_edges + 1, pts_xy, 2 * total * sizeof(double));
+  double *d_father = ctx->d_fe, *d_child = d_father + 3 * n_edges, *d_kt = d_child + 3 * n_edges;
+  unsigned long long *d_offs = reinterpret_cast<unsigned long long *>(d_kt + kMaxKt);
+  double *d_pts = d_kt + kMaxKt + n_edges + 1;
   hipStream_t st = ctx->stream;
-  HIPCHK(hipMemcpyAsync(d_father, father_states, 3 * n_edges * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(d_child, child_states, 3 * n_edges * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(d_pts, pts_xy, 2 * total * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(d_kt, kt_tab, nkt * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->d_fe_offs, offs.data(), (n_edges + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->d_fe_flag, flags.data(), n_edges * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->d_fe, h, need * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(ctx->d_fe_flag, 0, n_edges * sizeof(int), st));   // hit flags: 1 = some sdf < 0
   const dim3 grid((unsigned)n_edges, (unsigned)((max_pts + kSubswPoints - 1) / kSubswPoints));
-#define CALL(S)                                                                                              \
-  hipLaunchKernelGGL((k_subsw<S>), grid, dim3(kSubswBlock), 0, st, ctx->sp, d_father, d_child, ctx->d_fe_offs, \
+#define CALL(S)                                                                                         \
+  hipLaunchKernelGGL((k_subsw<S>), grid, dim3(kSubswBlock), 0, st, ctx->sp, d_father, d_child, d_offs,  \
                      d_pts, d_kt, nkt, ctx->d_fe_flag)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_fe_flag, n_edges * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(ctx->h_fe_flag.data(), ctx->d_fe_flag, n_edges * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (size_t e = 0; e < n_edges; ++e) free_out[e] = flags[e] ? 1 : 0;
+  for (size_t e = 0; e < n_edges; ++e) free_out[e] = ctx->h_fe_flag[e] ? 0 : 1;
   return SVSDF_OK;
 }
 

@@ -18,13 +18,13 @@ constexpr int kMaxKt = 64;         // interpolation steps per edge (the referenc
 
 // One block = one (edge, 64-point chunk).  LDS holds the edge's interpolated poses
 // linear_state(kt) = kt*child + (1-kt)*father (SWM:1191) with sin/cos of its yaw; lane = point, wave w takes
-// the steps w, w+4, ...  free_flag[e] starts at 1 and is cleared by any (point, step) with sdf < 0
+// the steps w, w+4, ...  hit_flag[e] starts at 0 and is set by any (point, step) with sdf < 0
 // (SWM:1201-1204: `min_sdf < 0` can only become true through the current temp_sdf).
 template <int SHAPE>
 __global__ void __launch_bounds__(kSubswBlock)
 k_subsw(ShapeParams sp, const double *__restrict__ father, const double *__restrict__ child,
         const unsigned long long *__restrict__ offs, const double *__restrict__ pts_xy,
-        const double *__restrict__ kt_tab, int nkt, int *__restrict__ free_flag) {
+        const double *__restrict__ kt_tab, int nkt, int *__restrict__ hit_flag) {
   __shared__ double s_x[kMaxKt], s_y[kMaxKt], s_c[kMaxKt], s_s[kMaxKt];
   const unsigned e = blockIdx.x;
   const unsigned long long p0 = offs[e], p1 = offs[e + 1];
@@ -55,7 +55,7 @@ k_subsw(ShapeParams sp, const double *__restrict__ father, const double *__restr
     }
   }
   if (__any(hit)) {
-    if (lane == 0) free_flag[e] = 0;
+    if (lane == 0) hit_flag[e] = 1;
   }
 }
 
