@@ -20,6 +20,7 @@
 #include "../../include/svsdf_c.h"
 #include "svsdf_kernels.hpp"
 #include "svsdf_frontend.hpp"
+#include "svsdf_lbfgs.hpp"
 #include "svsdf_minco.hpp"
 #include "svsdf_points.hpp"
 
@@ -1120,3 +1121,40 @@ int svsdf_last_costs(const svsdf_ctx *ctx, double costs3[3]) {
 }
 
 }  // extern "C"
+
+// ---- optimizer driver (host) ---------------------------------------------------
+void svsdf_lbfgs_params_default(svsdf_lbfgs_params *p) {
+  if (!p) return;
+  p->mem_size = 8; p->g_epsilon = 1.0e-5; p->past = 3; p->delta = 1.0e-6; p->max_iterations = 0;
+  p->max_linesearch = 64; p->min_step = 1.0e-20; p->max_step = 1.0e+20; p->f_dec_coeff = 1.0e-4;
+  p->s_curv_coeff = 0.9; p->cautious_factor = 1.0e-6; p->machine_prec = 1.0e-16;
+}
+
+int svsdf_lbfgs_minimize(int n, double *x, svsdf_evaluate_t eval, void *instance, svsdf_progress_t progress,
+                         void *progress_user, const svsdf_lbfgs_params *params, double *final_cost,
+                         int *iterations, int *evaluations) {
+  if (!x || !eval) return SVSDF_LBFGSERR_INVALIDPARAMETERS;
+  svsdf_lbfgs_params p;
+  if (params) p = *params; else svsdf_lbfgs_params_default(&p);
+  const svsdf_host::LbfgsResult r = svsdf_host::lbfgs_minimize(n, x, eval, instance, progress, progress_user, p);
+  if (final_cost) *final_cost = r.fx;
+  if (iterations) *iterations = r.iterations;
+  if (evaluations) *evaluations = r.evaluations;
+  return r.status;
+}
+
+int svsdf_optimize_traj(svsdf_ctx *ctx, double *x, int n, const svsdf_lbfgs_params *params,
+                        svsdf_progress_t progress, void *progress_user, double *final_cost, int *iterations,
+                        int *evaluations) {
+  if (!ctx || !x || n < 1 || (n + 3) % 4 != 0) {
+    fail(ctx, SVSDF_ERR_INVALID, "svsdf_optimize_traj: n must be N + 3(N-1)");
+    return SVSDF_LBFGSERR_INVALIDPARAMETERS;
+  }
+  // As in the reference, the side outputs (svsdf_last_costs, MINCO state) are those of the LAST callback
+  // evaluation -- after a failed line search that is a trial point, not the returned x -- and the objective is
+  // history dependent once a trial's total duration reaches 300 s (stale traj_duration, sw_manager.hpp:380-384):
+  // the value reported is the one the driver accepted, no re-evaluation is made here.
+  const int rc = svsdf_lbfgs_minimize(n, x, svsdf_lmbm_evaluate, ctx, progress, progress_user, params, final_cost,
+                                      iterations, evaluations);
+  return rc;
+}

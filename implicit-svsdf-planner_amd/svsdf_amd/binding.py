@@ -25,7 +25,24 @@ EXPORTS = [
     "svsdf_shard_plan", "svsdf_lmbm_prepare", "svsdf_debug_sincos_mismatches",
     "svsdf_map_create", "svsdf_map_destroy", "svsdf_map_info", "svsdf_map_gather", "svsdf_pcd_read_ascii",
     "svsdf_check_sub_sw_collision", "svsdf_shape_kernels",
+    "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
 ]
+
+
+class LbfgsParams(C.Structure):
+    """svsdf_lbfgs_params (include/svsdf_c.h), field for field lbfgs_parameter_t of the reference."""
+    _fields_ = [("mem_size", C.c_int), ("g_epsilon", C.c_double), ("past", C.c_int), ("delta", C.c_double),
+                ("max_iterations", C.c_int), ("max_linesearch", C.c_int), ("min_step", C.c_double),
+                ("max_step", C.c_double), ("f_dec_coeff", C.c_double), ("s_curv_coeff", C.c_double),
+                ("cautious_factor", C.c_double), ("machine_prec", C.c_double)]
+
+
+EVALUATE_T = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+PROGRESS_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                         C.c_int, C.c_int, C.c_int)
+LBFGS_STATUS = {0: "CONVERGENCE", 1: "STOP", 2: "CANCELED", -1012: "INVALID_FUNCVAL", -1011: "MINIMUMSTEP",
+                -1010: "MAXIMUMSTEP", -1009: "MAXIMUMLINESEARCH", -1008: "MAXIMUMITERATION", -1007: "WIDTHTOOSMALL",
+                -1006: "INVALIDPARAMETERS", -1005: "INCREASEGRADIENT"}
 
 
 class Config(C.Structure):
@@ -106,6 +123,13 @@ def lib():
     L.svsdf_pcd_read_ascii.argtypes = [C.c_char_p, _fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.svsdf_debug_sincos_mismatches.restype = C.c_longlong
     L.svsdf_debug_sincos_mismatches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+    L.svsdf_lbfgs_params_default.argtypes = [C.POINTER(LbfgsParams)]
+    L.svsdf_lbfgs_params_default.restype = None
+    _ip = C.POINTER(C.c_int)
+    L.svsdf_lbfgs_minimize.argtypes = [C.c_int, _dp, EVALUATE_T, C.c_void_p, PROGRESS_T, C.c_void_p,
+                                       C.POINTER(LbfgsParams), _dp, _ip, _ip]
+    L.svsdf_optimize_traj.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(LbfgsParams), PROGRESS_T, C.c_void_p,
+                                      _dp, _ip, _ip]
     _u8p = C.POINTER(C.c_ubyte)
     L.svsdf_check_sub_sw_collision.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, C.POINTER(C.c_size_t), _dp, _u8p]
     L.svsdf_shape_kernels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p, _dp,
@@ -221,6 +245,43 @@ def shard_plan(xyz, rank, world_size, flags=0):
     if rc:
         raise SvsdfError(f"svsdf_shard_plan failed: {rc}")
     return idx[:n.value].copy()
+
+
+def lbfgs_params(**kw):
+    p = LbfgsParams()
+    lib().svsdf_lbfgs_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown L-BFGS parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def _wrap_progress(progress):
+    if progress is None:
+        return C.cast(None, PROGRESS_T)
+
+    def _cb(_user, x, g, fx, step, n, k, ls):
+        xs = np.ctypeslib.as_array(x, shape=(n,)).copy()
+        gs = np.ctypeslib.as_array(g, shape=(n,)).copy()
+        return int(bool(progress(xs, gs, fx, step, k, ls)))
+    return PROGRESS_T(_cb)
+
+
+def lbfgs_minimize(fun, x0, progress=None, **params):
+    """Generic driver over a Python callable fun(x) -> (f, g).  Returns (x, f, status, iterations, evaluations)."""
+    x = _f64(x0).copy()
+    n = len(x)
+
+    def _ev(_inst, xp, gp, nn):
+        f, g = fun(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+        return float(f)
+    p = lbfgs_params(**params)
+    f, it, ev = C.c_double(0.0), C.c_int(0), C.c_int(0)
+    rc = lib().svsdf_lbfgs_minimize(n, _p(x), EVALUATE_T(_ev), None, _wrap_progress(progress), None, C.byref(p),
+                                    C.byref(f), C.byref(it), C.byref(ev))
+    return x, f.value, rc, it.value, ev.value
 
 
 class SvsdfContext:
@@ -361,6 +422,18 @@ class SvsdfContext:
         idx = self.shard_indices()
         order = np.argsort(idx, kind="stable")
         return sdf[order], ts[order], g[order], idx[order]
+
+    # ---- optimizer driver ----
+    def optimize_traj(self, x, progress=None, **params):
+        """optimize_traj_lmbm analogue (back_end_optimizer.cpp:3-95) with the in-library L-BFGS driver.
+        Returns (x_opt, final_cost, status, iterations, evaluations)."""
+        x = _f64(x).copy()
+        p = lbfgs_params(**params)
+        f, it, ev = C.c_double(0.0), C.c_int(0), C.c_int(0)
+        cb = _wrap_progress(progress)
+        rc = self.L.svsdf_optimize_traj(self.ctx, _p(x), len(x), C.byref(p), cb, None, C.byref(f), C.byref(it),
+                                        C.byref(ev))
+        return x, f.value, rc, it.value, ev.value
 
     # ---- front end (SURVEY.md §8 row f3) ----
     def check_sub_sw_collision(self, father_states, child_states, points_per_edge):

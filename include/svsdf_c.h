@@ -149,6 +149,55 @@ int svsdf_lmbm_begin(svsdf_ctx *ctx, const double *x, int n, double **d_partial,
 int svsdf_lmbm_prepare(svsdf_ctx *ctx, const double *x, int n, double *coeffs_out, double *T_out);
 double svsdf_lmbm_finish(svsdf_ctx *ctx, const double *partial_host, double *g, int n);
 
+/* ---- optimizer driver (host) ------------------------------------------------------- */
+/* A limited-memory BFGS driver with the Lewis-Overton weak-Wolfe line search so that the callback can be
+ * run end to end without the reference's Fortran LMBM (TrajOptimizer::optimize_traj_lmbm,
+ * src/planner_algorithm/src/back_end_optimizer.cpp:3-95 -> lmbm::lmbm_optimize, src/utils/include/utils/lmbm.h:
+ * 214-220).  Field names, defaults and status codes follow lbfgs_parameter_t / the LBFGS* enum of
+ * src/utils/include/utils/lbfgs.hpp:33-160 (the solver the reference's mid end uses).  It is NOT the bundle
+ * method: iterates differ from LMBM's, the objective and gradient it is fed are the same. */
+typedef struct svsdf_lbfgs_params {
+  int mem_size;           /* 8 */
+  double g_epsilon;       /* 1e-5: stop when |g|_inf / max(1, |x|_inf) <= g_epsilon */
+  int past;               /* 3 */
+  double delta;           /* 1e-6: stop when the relative decrease over `past` iterations < delta */
+  int max_iterations;     /* 0 = unlimited */
+  int max_linesearch;     /* 64 */
+  double min_step;        /* 1e-20 */
+  double max_step;        /* 1e+20 */
+  double f_dec_coeff;     /* 1e-4 */
+  double s_curv_coeff;    /* 0.9 */
+  double cautious_factor; /* 1e-6 */
+  double machine_prec;    /* 1e-16 */
+} svsdf_lbfgs_params;
+enum svsdf_lbfgs_status {
+  SVSDF_LBFGS_CONVERGENCE = 0, SVSDF_LBFGS_STOP = 1, SVSDF_LBFGS_CANCELED = 2,
+  SVSDF_LBFGSERR_UNKNOWNERROR = -1024, SVSDF_LBFGSERR_INVALID_N, SVSDF_LBFGSERR_INVALID_MEMSIZE,
+  SVSDF_LBFGSERR_INVALID_GEPSILON, SVSDF_LBFGSERR_INVALID_TESTPERIOD, SVSDF_LBFGSERR_INVALID_DELTA,
+  SVSDF_LBFGSERR_INVALID_MINSTEP, SVSDF_LBFGSERR_INVALID_MAXSTEP, SVSDF_LBFGSERR_INVALID_FDECCOEFF,
+  SVSDF_LBFGSERR_INVALID_SCURVCOEFF, SVSDF_LBFGSERR_INVALID_MACHINEPREC, SVSDF_LBFGSERR_INVALID_MAXLINESEARCH,
+  SVSDF_LBFGSERR_INVALID_FUNCVAL, SVSDF_LBFGSERR_MINIMUMSTEP, SVSDF_LBFGSERR_MAXIMUMSTEP,
+  SVSDF_LBFGSERR_MAXIMUMLINESEARCH, SVSDF_LBFGSERR_MAXIMUMITERATION, SVSDF_LBFGSERR_WIDTHTOOSMALL,
+  SVSDF_LBFGSERR_INVALIDPARAMETERS, SVSDF_LBFGSERR_INCREASEGRADIENT
+};
+/* Same shape as lmbm_evaluate_t (lmbm.h:206-209): returns f(x), overwrites g[0..n). */
+typedef double (*svsdf_evaluate_t)(void *instance, const double *x, double *g, const int n);
+/* Called after every accepted iteration k (ls = evaluations of its line search); non-zero return cancels
+ * (cf. lmbm_progress_t lmbm.h:211-213 and earlyExitLMBM, back_end_optimizer.hpp:1068-1085). */
+typedef int (*svsdf_progress_t)(void *user, const double *x, const double *g, double fx, double step, int n,
+                                int k, int ls);
+void svsdf_lbfgs_params_default(svsdf_lbfgs_params *params);
+/* Generic driver: minimise eval over R^n starting from x (in/out).  Returns a status of enum svsdf_lbfgs_status. */
+int svsdf_lbfgs_minimize(int n, double *x, svsdf_evaluate_t eval, void *instance, svsdf_progress_t progress,
+                         void *progress_user, const svsdf_lbfgs_params *params, double *final_cost,
+                         int *iterations, int *evaluations);
+/* optimize_traj_lmbm analogue: drives svsdf_lmbm_evaluate (points must be set) from x = [tau, q] in/out;
+ * afterwards svsdf_lmbm_prepare(ctx, x, ...) gives the MINCO coefficients of the result (svsdf_last_costs
+ * reflects the last callback evaluation, which is the returned point unless the final line search failed).  params may be NULL (defaults).  Returns a status of enum svsdf_lbfgs_status; values >= 0 mean a usable result. */
+int svsdf_optimize_traj(svsdf_ctx *ctx, double *x, int n, const svsdf_lbfgs_params *params,
+                        svsdf_progress_t progress, void *progress_user, double *final_cost, int *iterations,
+                        int *evaluations);
+
 /* ---- front-end consumers of the same shape SDFs (device) ------------------------- */
 /* Replaces SweptVolumeManager::checkSubSWCollision (src/swept_volume/include/swept_volume/sw_manager.hpp:
  * 1171-1211), batched: the reference calls it once per A* edge from AstarPathSearcher::AstarGetSucc

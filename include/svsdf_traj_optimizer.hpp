@@ -94,6 +94,24 @@ class TrajOptimizerHip {
     return svsdf_eval_penalty(ctx, N, coeffs, T, &cost, gradT, gradC);
   }
 
+  // optimize_traj_lmbm (back_end_optimizer.cpp:3-95) with the library's L-BFGS driver in place of
+  // lmbm::lmbm_optimize: initS/finalS 3x3 col-major, opt_x[N + 3(N-1)] in/out.  Returns the solver status
+  // (>= 0 success, with 0 mapped to 1 like back_end_optimizer.cpp:62-65); final_cost may be null.
+  int optimize_traj_lmbm(const double initS[9], const double finalS[9], double *opt_x, const int N,
+                         double *final_cost = nullptr, const svsdf_lbfgs_params *param = nullptr) {
+    setConditions(initS, finalS, N);
+    svsdf_ctx *ctx = context();
+    if (!ctx) return SVSDF_LBFGSERR_INVALIDPARAMETERS;
+    int ret = svsdf_optimize_traj(ctx, opt_x, temporalDim + spatialDim, param, nullptr, nullptr, final_cost,
+                                  &iter, nullptr);
+    double c3[3] = {0, 0, 0};
+    svsdf_last_costs(ctx, c3);  // of the last callback evaluation, like the reference's members
+    cost_pos = c3[0]; cost_other = c3[1]; cost_total = c3[2];
+    if (ret == 0) ret = 1;
+    return ret;
+  }
+  int iter = 0;  // iterations of the last optimize_traj_lmbm (TrajOptimizer::iter, back_end_optimizer.hpp)
+
 #ifdef SVSDF_HAVE_EIGEN
   static void addSaftyPenaOnSweptVolumeParallelTrueSDF(void *ptr, const Eigen::VectorXd &T,
                                                        const Eigen::MatrixX3d &coeffs, double &cost,

@@ -1,7 +1,8 @@
 // Drives the C++ mirror (include/svsdf_traj_optimizer.hpp) exactly like the reference's
 // optimize_traj_lmbm drives TrajOptimizer: a raw lmbm_evaluate_t function pointer + void* instance.
 // Input (stdin): shape_inputdata safety_hor weight_p rho N P, then 9+9 state doubles, n x-doubles,
-// 3P point doubles.  Output: cost, cost_pos, cost_other, cost_total, then g[0..n).
+// 3P point doubles.  Output: cost, cost_pos, cost_other, cost_total, then g[0..n); with --optimize also
+// ret, iterations, final cost, cost_total and the optimised x[0..n).
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -35,5 +36,18 @@ int main(int argc, char **argv) {
   const double f = eval(&opt, x.data(), g.data(), n);
   std::printf("%.17g %.17g %.17g %.17g\n", f, opt.cost_pos, opt.cost_other, opt.cost_total);
   for (int i = 0; i < n; ++i) std::printf("%.17g\n", g[i]);
+  if (argc > 1 && std::string(argv[1]) == "--optimize") {
+    // optimize_traj_lmbm(initS, finalS, opt_x, N, traj) call shape of plan_manager.cpp:176
+    svsdf_lbfgs_params prm;
+    svsdf_lbfgs_params_default(&prm);
+    prm.max_iterations = 15;
+    double final_cost = 0.0;
+    svsdf::TrajOptimizerHip opt2;
+    opt2.inputdata = name; opt2.safety_hor = sh; opt2.weight_p = wp; opt2.rho = rho; opt2.device = 0;
+    opt2.setPoints(pts.data(), (size_t)P);
+    const int ret = opt2.optimize_traj_lmbm(hs, ts, x.data(), N, &final_cost, &prm);
+    std::printf("%d %d %.17g %.17g\n", ret, opt2.iter, final_cost, opt2.cost_total);
+    for (int i = 0; i < n; ++i) std::printf("%.17g\n", x[i]);
+  }
   return 0;
 }

@@ -38,8 +38,10 @@ def test_cpp_mirror_matches_ctypes_path(built):
     inp += col(w["head_state"]) + "\n" + col(w["tail_state"]) + "\n"
     inp += " ".join(repr(float(v)) for v in x) + "\n"
     inp += " ".join(repr(float(v)) for v in w["points"].ravel()) + "\n"
-    out = subprocess.run([exe], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split()
-    vals = np.array([float(v) for v in out])
+    out = subprocess.run([exe, "--optimize"], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split()
+    n = len(x)
+    vals = np.array([float(v) for v in out[:4 + n]])
+    opt = out[4 + n:]
     ctx = svsdf_amd.SvsdfContext(shape="star", safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
                                  head_state=w["head_state"], tail_state=w["tail_state"], device=0)
     ctx.set_points(w["points"])
@@ -47,3 +49,9 @@ def test_cpp_mirror_matches_ctypes_path(built):
     assert abs(vals[0] - f) <= 1e-12 * abs(f)
     np.testing.assert_allclose(vals[1:4], ctx.last_costs(), rtol=1e-12)
     np.testing.assert_allclose(vals[4:], g, rtol=1e-9, atol=1e-9)
+    # optimize_traj_lmbm through the mirror == optimize_traj through ctypes (same library, same driver)
+    xo, fo, rc, it, _ = ctx.optimize_traj(x, max_iterations=15)
+    assert int(opt[0]) == (1 if rc == 0 else rc) and int(opt[1]) == it
+    assert abs(float(opt[2]) - fo) <= 1e-8 * abs(fo)   # LDS-atomic sum order differs run to run (~1e-12 per call)
+    np.testing.assert_allclose([float(v) for v in opt[4:]], xo, rtol=0, atol=1e-6)
+    assert fo < f
