@@ -111,13 +111,13 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    evals = scan = solves = launches = interior = samples = 0
+    evals = scan = solves = launches = interior = samples = culled = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
         st = ctx.stats()
         evals += st["sdf_evals"]; scan += st["scan_evals"]; solves += st["solves"]
-        launches += st["solve_launches"]; interior = st["interior_points"]; samples += st["gsip_samples"]
+        launches += st["solve_launches"]; interior = st["interior_points"]; samples += st["gsip_samples"]; culled = st["culled_points"]
     fence()
     elapsed = time.perf_counter() - t0
     # kernel times of the dominant kernel: separate passes with per-launch HIP events on the
@@ -169,6 +169,7 @@ def main():
                    "interior_fraction": interior_all / a.steps / P_total,
                    "argmin_solves_per_point": solves_all / a.steps / P_total,
                    "gsip_samples_per_point_rank0": samples / a.steps / max(ctx.num_points(), 1),
+                   "culled_fraction_rank0": culled / max(ctx.num_points(), 1),
                    "parallelism": f"points striped over {world} GPU(s), 1 all-reduce of {19 * N + 1} f64"},
         "roofline": {"bound": "hbm", "kernel": "k_solve (argmin over t: pruned table scan + scan layers 2-4 + descent; all launches of one evaluation)",
                      "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,

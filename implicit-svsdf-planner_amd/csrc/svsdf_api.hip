@@ -66,6 +66,8 @@ struct svsdf_ctx {
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
   int late_iter = 4, first_iters = 12, it_done = 0, U = 1, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
+  bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
+  bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
   int G_env = 0;
   double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
@@ -106,7 +108,7 @@ struct svsdf_ctx {
 namespace {
 
 constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 8;
+constexpr size_t kOutDoubles = kOutPartial + 9;
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -182,7 +184,7 @@ size_t table_lds_doubles(const svsdf_ctx *ctx) {
 
 template <int S, int G, int U>
 void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries, double *out_sdf,
-                     double *out_t, BatchCtl *ctl, int work_idx) {
+                     double *out_t, BatchCtl *ctl, int work_idx, double cull_thresh) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
   const int blk = ctx->block;
@@ -191,7 +193,7 @@ void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long lo
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   hipLaunchKernelGGL((k_solve<S, G, U>), dim3(grid), dim3(blk), lds, st, ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks,
-                     ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx);
+                     ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -202,22 +204,22 @@ void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long lo
 
 template <int S>
 void launch_solve_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, double *out_sdf,
-                    double *out_t, BatchCtl *ctl, int work_idx) {
-  // G lanes per query, U interleaved evaluations per lane (G * U candidates / samples per step)
-  switch (G * 10 + ctx->U) {
-    case 11: launch_solve_sg<S, 1, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
-    case 21: launch_solve_sg<S, 2, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
-    case 22: launch_solve_sg<S, 2, 2>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
-    case 42: launch_solve_sg<S, 4, 2>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
-    case 81: launch_solve_sg<S, 8, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
-    case 82: launch_solve_sg<S, 8, 2>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
-    default: launch_solve_sg<S, 4, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx); break;
+                    double *out_t, BatchCtl *ctl, int work_idx, double cull_thresh) {
+  // G lanes per query (G candidates / samples per step); the U = 2 interleaving (two evaluations per lane) was
+  // measured and dropped, only U = 1 is instantiated
+  switch (G) {
+    case 1: launch_solve_sg<S, 1, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
+    case 2: launch_solve_sg<S, 2, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
+    case 8: launch_solve_sg<S, 8, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
+    case 16: launch_solve_sg<S, 16, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
+    default: launch_solve_sg<S, 4, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
   }
 }
 
 void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, double *out_sdf,
-                  double *out_t, BatchCtl *ctl, int work_idx) {
-#define CALL(S) launch_solve_s<S>(ctx, G, st, qs, mq, out_sdf, out_t, ctl, work_idx)
+                  double *out_t, BatchCtl *ctl, int work_idx,
+                  double cull_thresh = std::numeric_limits<double>::infinity()) {
+#define CALL(S) launch_solve_s<S>(ctx, G, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh)
   SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
 }
@@ -275,7 +277,7 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   size_t K = 0;
   for (double t = 0.0; t <= dur; t += 0.15) ++K;
   if (K > 16000) return fail(ctx, SVSDF_ERR_INVALID, "trajectory duration too long for the scan table");
-  const size_t need = 19 * (size_t)N + K;
+  const size_t need = 19 * (size_t)N + K + (K + kChunk - 1) / kChunk;  // coeffs | T | tk | chunk slack
   if (need > ctx->in_cap) {
     const size_t cap = need + 4096;
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
@@ -301,6 +303,52 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   }
   for (size_t i = 0; i < 19 * (size_t)N; ++i)
     if (!std::isfinite(ctx->h_in[i])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite trajectory input");
+  {
+    // Exact cull (k_solve, main points): a point is skipped when  min_c(|p - c_c| - rb_c - slack_c) > safety_hor.
+    // Chunk c holds the table times t_k0 .. t_k1; every t of [t_k0 - h, t_k1 + h] lies within h of one of them
+    // (h = half the table spacing; the last chunk also covers (t_last, dur]), so |x(t) - x(t_k)| <= V_c * h with
+    // V_c a rigorous bound of the planar speed on that interval: the quartic velocity polynomials lie in the
+    // convex hull of their Bernstein coefficients on the sub-interval.  Then sdf(t) >= |p - x(t)| - R_shape >=
+    // |p - c_c| - rb_c - V_c * h for every continuous t, whatever local minimum the reference's search returns,
+    // and smoothedL1 (BEO:316-340) is inactive.  Only in the regular regime (traj_duration not stale).
+    const size_t nch = (K + kChunk - 1) / kChunk;
+    double *slack = ctx->h_in + 19 * (size_t)N + K;
+    const double *tk = ctx->h_in + 19 * (size_t)N;
+    ctx->cull_ok = (td == dur) && K >= 1;
+    std::vector<double> S(N + 1, 0.0);
+    for (int i = 0; i < N; ++i) S[i + 1] = S[i] + T[i];
+    for (size_t c = 0; c < nch; ++c) {
+      slack[c] = std::numeric_limits<double>::infinity();
+      if (!ctx->cull_ok) continue;
+      const size_t k0 = c * kChunk, k1 = std::min(k0 + kChunk, K) - 1;
+      const double h = (c + 1 == nch) ? std::max(0.0751, dur - tk[k1]) : 0.0751;
+      const double ta = std::max(0.0, tk[k0] - h), tb = std::min(td, tk[k1] + h);
+      double v2 = 0.0;
+      for (int i = 0; i < N; ++i) {
+        const double a = std::max(ta, S[i]) - S[i], b = std::min(tb, S[i + 1]) - S[i];  // local times in piece i
+        if (!(b >= a)) continue;
+        const double w = b - a;
+        double bound[2] = {0.0, 0.0};
+        for (int d = 0; d < 2; ++d) {
+          double p[5];  // velocity in s: p[k] = (k+1) c_{k+1}
+          for (int k = 0; k < 5; ++k) p[k] = (k + 1) * coeffs[(size_t)d * 6 * N + 6 * i + k + 1];
+          for (int j = 0; j < 4; ++j)          // Taylor shift s = a + s' (repeated synthetic division)
+            for (int k = 3; k >= j; --k) p[k] += a * p[k + 1];
+          double wp = 1.0;
+          for (int k = 0; k < 5; ++k) { p[k] *= wp; wp *= w; }   // s' = w u, u in [0, 1]
+          static const double binom4[5] = {1, 4, 6, 4, 1};
+          for (int j = 0; j <= 4; ++j) {
+            double bj = 0.0, cjq = 1.0;  // C(j, q)
+            for (int q = 0; q <= j; ++q) { bj += cjq / binom4[q] * p[q]; cjq = cjq * (j - q) / (q + 1); }
+            bound[d] = std::max(bound[d], std::fabs(bj));
+          }
+        }
+        v2 = std::max(v2, std::hypot(bound[0], bound[1]));
+      }
+      const double sl = v2 * (1.0 + 1e-9) * h + 1e-9;
+      if (std::isfinite(sl)) slack[c] = sl;
+    }
+  }
   ctx->N = N;
   ctx->K = (int)K;
   HIPCHK(hipMemcpyAsync(ctx->d_in, ctx->h_in, need * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -339,7 +387,7 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
 
 // Enqueue the device pipeline up to the per-point results of getTrueSDFofSweptVolume (res_*).
 // No host synchronisation: batches run on their own streams, joined back onto ctx->stream.
-int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bool allow_cull) {
   if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
   if (ctx->P == 0) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
   HIPCHK(hipSetDevice(ctx->device));
@@ -360,7 +408,8 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     QuerySet qm{};
     qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
     qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
-    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0);
+    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0,
+                 (allow_cull && ctx->cull && ctx->cull_ok) ? ctx->cfg.safety_hor + 1e-9 : std::numeric_limits<double>::infinity());
     launch_classify(ctx, st, b);
     launch_round(ctx, st, b, 0);
   }
@@ -421,6 +470,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.interior_points = st[3];
   ctx->stats.gsip_samples = st[6];
   ctx->stats.gsip_iterations = (unsigned)st[7];
+  ctx->stats.culled_points = st[8];
   // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
   // covers an underestimate
   if (ctx->adaptive_iters) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
@@ -454,7 +504,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
 
 // Whole device pipeline; leaves [cost, gradC, gradT] (19N+1 doubles) in d_out / h_out.
 int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
-  int rc = enqueue_queries(ctx, N, coeffs, T);
+  int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/true);
   if (rc) return rc;
   return finish(ctx, true);
 }
@@ -664,8 +714,8 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     ctx->cfg.polygon_nverts = sp.nverts;
   }
   ctx->G_env = 0;
-  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
-  if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) ctx->G_late = g; }
+  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
+  if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ctx->G_late = g; }
   if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
@@ -676,6 +726,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) ctx->select_delta = std::atof(e);
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
+  if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
   for (int b = 0; b < kMaxBatches; ++b) {
     if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||
@@ -788,7 +839,7 @@ int svsdf_eval_penalty(svsdf_ctx *ctx, int N, const double *coeffs, const double
 int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *sdf,
                        double *tstar, double *grad_xy) {
   if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_query_points: null argument");
-  int rc = enqueue_queries(ctx, N, coeffs, T);
+  int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/false);  // per-point outputs need every solve
   if (rc) return rc;
   rc = finish(ctx, false);
   if (rc) return rc;

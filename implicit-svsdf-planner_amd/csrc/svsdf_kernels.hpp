@@ -57,7 +57,7 @@ struct Pose { double x, y, cs, sn; };
 // samples, inflated by the shape's bound radius R (sdf_shape(q) >= |q| - R for every q), so
 // that  sdf(sample) >= |p - c| - rb  for every sample of the chunk.
 constexpr int kChunk = 8;
-struct Chunk { double cx, cy, rb, pad; };
+struct Chunk { double cx, cy, rb, slack; };  // slack: continuous-path allowance V_c * h for the exact cull (host)
 
 // Per-batch control block (device memory; the counters are cleared by k_prep at the start of
 // every evaluation, start/count are written by the host once per point upload).
@@ -69,7 +69,7 @@ struct BatchCtl {
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
   int pad;
-  unsigned long long stat_solves, stat_evals, stat_scan;
+  unsigned long long stat_solves, stat_evals, stat_scan, stat_culled;
 };
 
 // LDS view of the trajectory
@@ -268,13 +268,13 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K,
                        Chunk *__restrict__ chunks, double r_bound, BatchCtl *__restrict__ ctl,
                        int nbatch) {
   extern __shared__ double prep_lds[];
-  const double *coeffs = in, *T = in + 18 * N, *tk = in + 19 * N;
+  const double *coeffs = in, *T = in + 18 * N, *tk = in + 19 * N, *slack = in + 19 * N + K;
   for (int b = threadIdx.x; b < nbatch; b += blockDim.x) {
     BatchCtl &c = ctl[b];
     for (int r = 0; r < kMaxIter + 2; ++r) { c.n_active[r] = 0; c.n_solve[r] = 0; c.n_seed[r] = 0; }
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
     c.nonfinite = 0;
-    c.stat_solves = 0ull; c.stat_evals = 0ull; c.stat_scan = 0ull;
+    c.stat_solves = 0ull; c.stat_evals = 0ull; c.stat_scan = 0ull; c.stat_culled = 0ull;
   }
   if (threadIdx.x == 0) {
     tr->N = N; tr->K = K; tr->dur = dur;
@@ -307,7 +307,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K,
     double r = 0.0;
     for (int k = k0; k < k1; ++k) r = fmax(r, norm2(pose[k].x - cx, pose[k].y - cy));
     Chunk ch;
-    ch.cx = cx; ch.cy = cy; ch.rb = r * (1.0 + 1e-12) + r_bound + 1e-9; ch.pad = 0.0;
+    ch.cx = cx; ch.cy = cy; ch.rb = r * (1.0 + 1e-12) + r_bound + 1e-9; ch.slack = slack[c];
     chunks[c] = ch;
   }
 }
@@ -424,7 +424,7 @@ template <int SHAPE, int G, int U>
 __global__ void __launch_bounds__(kBlock, SVSDF_SOLVE_WAVES)
 k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
-        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx) {
+        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh) {
   extern __shared__ double solve_lds[];
   int n;
   const long long total = qs_total(qs, n);
@@ -442,7 +442,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   const TrajL tr = stage_traj(trg, solve_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
   const int li = Grp<G>::li();
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
-  unsigned n_eval = 0, n_scan = 0, n_solved = 0;
+  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0;
 #ifdef SVSDF_TIMING
   long long tm_scan = 0, tm_lay = 0, tm_gd = 0, tm_steps = 0, tm_start = wall_clock64();
 #endif
@@ -465,6 +465,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     // ---- choiceTInit layer 1 over the pose table
     double best_d = 1e9;   // min_dis initial value (SWM:545)
     int best_k = 0x7fffffff;
+    bool culled = false;
     auto eval_chunk = [&](int c) {
       double d_loc = 1e300;
       int k_loc = 0x7fffffff;
@@ -486,18 +487,28 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       for (int c = 0; c < nch; ++c) eval_chunk(c);
     } else {
       // 1. the chunk with the smallest lower bound gives the first upper bound
-      double lb_loc = 1e300;
+      double lb_loc = 1e300, lbc_loc = 1e300;
       int c_loc = 0;
       for (int c = li; c < nch; c += G) {
         const Chunk ch = chunks[c];
         const double lb = norm2(px - ch.cx, py - ch.cy) - ch.rb;
         if (lb < lb_loc) { lb_loc = lb; c_loc = c; }
+        lbc_loc = dmin(lbc_loc, lb - ch.slack);
       }
       Grp<G>::min_dk(lb_loc, c_loc);
+      if constexpr (G > 1) {
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) lbc_loc = dmin(lbc_loc, __shfl_xor(lbc_loc, m, G));
+      }
+      // exact cull (main points only; cull_thresh = +inf otherwise): every pose of the continuous path keeps
+      // sdf >= lbc_loc > safety_hor (upload_traj), so smoothedL1 is inactive (BEO:316-340, x < 0) whatever
+      // local minimum the reference's search would return: the point contributes exactly zero
+      culled = lbc_loc > cull_thresh;
+      if (culled) { best_d = lbc_loc; best_k = 0; }
       const int c0 = c_loc;
-      eval_chunk(c0);
+      if (!culled) eval_chunk(c0);
       // 2. every other chunk whose lower bound does not exceed the running minimum
-      int c = 0;
+      int c = culled ? nch : 0;
       while (c < nch) {
         const int cc = c + li;
         bool need = false;
@@ -513,6 +524,9 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
         c = c + first + 1;
       }
     }
+    if (culled) {
+      if (li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
+    } else {
     PieceCache piece = piece_cache_init();
     double time_seed = tk[best_k];
     double min_dis = best_d;
@@ -647,6 +661,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 #ifdef SVSDF_TIMING
     { const long long tq3 = wall_clock64(); tm_scan += tq1 - tq0; tm_lay += tq2 - tq1; tm_gd += tq3 - tq2; }
 #endif
+    }  // !culled
     }  // live
   }
 #ifdef SVSDF_TIMING
@@ -659,13 +674,14 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     atomicMax(&tmo[6], (unsigned long long)(wall_clock64() - tm_start));
   }
 #endif
-  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan;
+  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tu = n_culled;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
-    te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64);
+    te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tu += __shfl_xor(tu, m, 64);
   }
-  if ((threadIdx.x & 63) == 0 && te) {
+  if ((threadIdx.x & 63) == 0 && (te || tu)) {
     atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); atomicAdd(&ctl->stat_scan, tc);
+    if (tu) atomicAdd(&ctl->stat_culled, tu);
   }
 }
 
@@ -1079,9 +1095,9 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
   if (threadIdx.x == 0) {
     double suf = 0.0;
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
-    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0;
+    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0;
     for (int b = 0; b < nbatch; ++b) {
-      so += ctl[b].stat_solves; ev += ctl[b].stat_evals; sc += ctl[b].stat_scan;
+      so += ctl[b].stat_solves; ev += ctl[b].stat_evals; sc += ctl[b].stat_scan; cu += ctl[b].stat_culled;
       in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
       rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
       for (int i = 0; i <= it_end; ++i) {
@@ -1090,7 +1106,7 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
       }
     }
     stats_out[0] = so; stats_out[1] = ev; stats_out[2] = sc; stats_out[3] = in; stats_out[4] = nf;
-    stats_out[5] = rem; stats_out[6] = seeded; stats_out[7] = iters;
+    stats_out[5] = rem; stats_out[6] = seeded; stats_out[7] = iters; stats_out[8] = cu;
   }
 }
 

@@ -256,12 +256,25 @@ __device__ inline double sdf_polygon(const ShapeParams &sp, double x, double y, 
     const double cx = sx + t * vx, cy = sy + t * vy;
     const double dis = norm2(x - cx, y - cy);
     if (dis < dis_min) { dis_min = dis; mx = cx; my = cy; }
-    // isCrossRayOnXDir
-    double theta_s = atan2(sy - y, sx - x);
-    double theta_e = atan2(ey - y, ex - x);
-    theta_s = (theta_s < 0.0) ? (theta_s + 2 * kPI) : theta_s;
-    theta_e = (theta_e < 0.0) ? (theta_e + 2 * kPI) : theta_e;
-    if (!(fabs(theta_s - theta_e) < kPI)) rs++;
+    // isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
+    // atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
+    // opposite signs of y and the vector with y > 0 leading the other by more than pi counter-clockwise, i.e.
+    // sign(cross(s2, e2)) -- decided without atan2 unless the angle difference is within ~1e-9 rad of 0 or pi
+    // (sin^2 <= 1e-18), where the rounding of the two atan2 values (~1e-16) could matter and the reference
+    // formula itself is evaluated.
+    const double s2x = sx - x, s2y = sy - y, e2x = ex - x, e2y = ey - y;
+    const double crs = s2x * e2y - s2y * e2x;
+    const double n2 = (s2x * s2x + s2y * s2y) * (e2x * e2x + e2y * e2y);
+    if (s2y != 0.0 && e2y != 0.0 && crs * crs > 1e-18 * n2) {
+      const bool sneg = s2y < 0.0, eneg = e2y < 0.0;
+      if ((sneg != eneg) && ((crs < 0.0) == eneg)) rs++;
+    } else {
+      double theta_s = atan2(s2y, s2x);
+      double theta_e = atan2(e2y, e2x);
+      theta_s = (theta_s < 0.0) ? (theta_s + 2 * kPI) : theta_s;
+      theta_e = (theta_e < 0.0) ? (theta_e + 2 * kPI) : theta_e;
+      if (!(fabs(theta_s - theta_e) < kPI)) rs++;
+    }
   }
   if (cminx) { *cminx = mx; *cminy = my; }
   return (rs % 2 == 0) ? dis_min : -dis_min;

@@ -56,7 +56,7 @@ class Stats(C.Structure):
     _fields_ = [("points", C.c_ulonglong), ("interior_points", C.c_ulonglong),
                 ("solves", C.c_ulonglong), ("gsip_samples", C.c_ulonglong), ("sdf_evals", C.c_ulonglong),
                 ("scan_evals", C.c_ulonglong), ("device_ms", C.c_double), ("solve_ms", C.c_double),
-                ("solve_launches", C.c_uint), ("gsip_iterations", C.c_uint)]
+                ("solve_launches", C.c_uint), ("gsip_iterations", C.c_uint), ("culled_points", C.c_ulonglong)]
 
 
 class SvsdfError(RuntimeError):

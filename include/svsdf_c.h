@@ -265,6 +265,7 @@ typedef struct svsdf_stats {
   double solve_ms;                    /* HIP-event time summed over the k_solve launches (profiling on) */
   unsigned int solve_launches;        /* k_solve launches of the last evaluation */
   unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
+  unsigned long long culled_points;   /* main queries proven inactive (sdf > safety_hor) without a solve */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 /* Per-launch HIP-event timing of the dominant (argmin refine) kernel on the library's own

@@ -125,3 +125,39 @@ def test_inlined_sincos_is_bit_identical_to_device_library(built):
                       (1.0e9, 1.2e9, 100_001), (-3.0e10, 3.0e10, 100_001), (0.0, 0.0 + 1e-12, 1001)):
         assert c.sincos_mismatches(lo, hi, n) == 0, (lo, hi)
     c.close()
+
+
+def test_exact_cull_is_invisible(built):
+    """The exact cull (points proven inactive from the chunk bounds plus a rigorous continuous-path allowance skip
+    the argmin solve) must not change cost or gradient, and may only ever drop points whose true
+    SVSDF exceeds safety_hor (checked against the un-culled per-point query)."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    for cfg, P in (("C2", 60000), ("C4", 40000), ("C5", 30000)):
+        w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
+
+        def run():
+            ctx = _ctx(w)
+            ctx.set_points(w["points"])
+            out = ctx.eval_penalty(w["coeffs"], w["T"])
+            st = ctx.stats()
+            sdf = ctx.query_points(w["coeffs"], w["T"])[0]   # query_points never culls
+            return out, st, sdf
+        (c0, gT0, gC0), st0, sdf0 = _with_env(dict(SVSDF_CULL=0), run)
+        (c1, gT1, gC1), st1, sdf1 = _with_env(dict(SVSDF_CULL=1), run)
+        inactive = int((sdf0 > w["safety_hor"]).sum())
+        assert st0["culled_points"] == 0 and 0 < st1["culled_points"] <= inactive
+        assert st1["solves"] == st0["solves"] - st1["culled_points"]
+        np.testing.assert_array_equal(sdf0, sdf1)
+        assert abs(c1 - c0) <= 1e-13 * abs(c0)                  # same non-zero terms; LDS-atomic order only
+        assert np.abs(gT1 - gT0).max() <= 1e-12 * np.abs(gT0).max()
+        assert np.abs(gC1 - gC0).max() <= 1e-12 * np.abs(gC0).max()
+    # stale-duration regime (total >= 300 s after a shorter trajectory): the cull switches itself off
+    w = workload.make("C2", P=20000, minco=svsdf_amd.minco_coeffs)
+    ctx = _ctx(w)
+    ctx.set_points(w["points"])
+    ctx.eval_penalty(w["coeffs"], w["T"])
+    assert ctx.stats()["culled_points"] > 0
+    Tlong = np.asarray(w["T"]) * 8.0                            # 320 s
+    ctx.eval_penalty(svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], w["q"], Tlong), Tlong)
+    assert ctx.stats()["culled_points"] == 0

@@ -9,7 +9,7 @@ w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
 ref = None
 for spec in sys.argv[3:]:
     env = dict(kv.split("=") for kv in spec.split(","))
-    for k in ("SVSDF_G","SVSDF_G_LATE","SVSDF_PRUNE","SVSDF_BATCHES","SVSDF_BLOCK","SVSDF_WAVES_PER_CU","SVSDF_PROFILE"):
+    for k in [k for k in os.environ if k.startswith("SVSDF_") and k != "SVSDF_LIB_VARIANT"]:
         os.environ.pop(k, None)
     os.environ.update(env)
     ctx = svsdf_amd.SvsdfContext(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
