@@ -84,6 +84,7 @@ def main():
     if world > 1 or os.environ.get("SVSDF_BENCH_FORCE_DIST"):   # the latter exercises the RCCL path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
