@@ -569,7 +569,18 @@ void shard_plan(const double *xyz, size_t P, int rk, int ws, int flags, std::vec
       const uint32_t qy = (uint32_t)std::min(65535.0, std::max(0.0, fy * 65535.0));
       key[i] = ((uint64_t)(part1by1(qx) | (part1by1(qy) << 1)) << 32) | (uint64_t)(i & 0xffffffffu);
     }
-    std::stable_sort(order.begin(), order.end(), [&](long long a, long long b) { return key[a] < key[b]; });
+    // order by (morton code, input index): LSD radix sort of the 32 Morton bits, 4 stable 8-bit passes over
+    // keys that start in index order (the low 32 bits carry the index and are never a sort digit)
+    std::vector<uint64_t> tmp(P);
+    for (int pass = 0; pass < 4; ++pass) {
+      const int sh = 32 + 8 * pass;
+      size_t cnt[257] = {0};
+      for (size_t i = 0; i < P; ++i) ++cnt[((key[i] >> sh) & 0xffu) + 1];
+      for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+      for (size_t i = 0; i < P; ++i) tmp[cnt[(key[i] >> sh) & 0xffu]++] = key[i];
+      key.swap(tmp);
+    }
+    for (size_t i = 0; i < P; ++i) order[i] = (long long)(key[i] & 0xffffffffull);
   }
   ws = std::max(1, ws);
   out.clear();
