@@ -165,3 +165,30 @@ def test_sharded_contexts_sum_to_whole(built):
     assert abs(acc_c - full[0]) <= 1e-10 * abs(full[0])
     np.testing.assert_allclose(acc_C, full[2], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(acc_T, full[1], rtol=1e-9, atol=1e-9)
+
+
+def _budget_points(evals_per_point, seconds=4.0):
+    """Points the oracle finishes in ~`seconds` on this host (~1.2e6 SDF evaluations/s per core, measured)."""
+    return int(seconds * 1.2e6 * NT / evals_per_point)
+
+
+@pytest.mark.parametrize("config,full,evals_pp", [("C2", 100000, 6500), ("C3", 1000000, 11000), ("C4", 500000, 11000),
+                                                  ("C5", 1000000, 20000)])
+def test_baseline_sizes_match_oracle(built, config, full, evals_pp):
+    """The BASELINE.json workloads at the largest size the oracle finishes in a few seconds on this host (all of
+    C2's 100 k points on a 256-core box): per-point SVSDF and t*, interior count, reduced cost and gradients.
+    One-off run at the full sizes (C2 100 k / C3 1 M / C4 500 k / C5 1 M, 256 cores, 7.5 min): basin flips
+    11 / 22 / 5 / 36, cost rel 5e-13 / 1e-14 / 1e-13 / 3e-14, gradC rel 2.4e-7 / 9.7e-9 / 1.7e-8 / 1.5e-9."""
+    P = max(2000, min(full, _budget_points(evals_pp)))
+    w, ctx, o = _mk(config, P)
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    ocost, ogT, ogC, osdf, ots, _ = o.penalty(w["points"], nthreads=NT, sum_mode=1, per_point=True)
+    flips = np.abs(ts - ots) > 1e-6
+    assert flips.mean() <= 2e-3, (int(flips.sum()), P)
+    assert np.abs(sdf[~flips] - osdf[~flips]).max() <= 1e-7
+    assert ctx.stats()["interior_points"] == o.counters()["interior_points"]
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost), (cost, ocost)
+    assert _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5, (_rel(gC, ogC), _rel(gT, ogT))
+    print(f"{config}: P = {P}, flips {int(flips.sum())}, cost rel {abs(cost - ocost) / abs(ocost):.2e}, "
+          f"gradC rel {_rel(gC, ogC):.2e}, gradT rel {_rel(gT, ogT):.2e}")
