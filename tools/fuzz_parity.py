@@ -1,0 +1,68 @@
+"""Differential fuzzing (GPU box): random shapes / shape offsets / trajectories / points, HIP path vs the oracle.
+Prints every case outside the gates (cost 1e-7 rel, gradient 1e-5 rel) or with > 1 % basin flips."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "implicit-svsdf-planner_amd")]
+import numpy as np, svsdf_amd
+from svsdf_amd import workload
+from oracle import orc
+NT = os.cpu_count() or 1
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+bad = 0
+worst = dict(cost=0.0, gC=0.0, gT=0.0, flips=0.0)
+t00 = time.time()
+for case in range(ncase):
+    rng = np.random.default_rng(seed0 * 100003 + case)
+    shape = orc.SHAPES[rng.integers(0, 17)]
+    pp = (0.0, 0.0, 0.0) if rng.random() < 0.4 else (rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-180, 180))
+    poly = None
+    if shape == "Polygon":
+        k = int(rng.integers(3, 9))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        rad = rng.uniform(0.8, 3.0, k)
+        poly = np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
+    N = int(rng.integers(1, 7))
+    T = rng.uniform(0.3, 4.0, N)
+    kind = rng.integers(0, 4)
+    start = rng.uniform(0, 20, 2)
+    end = start + (rng.uniform(-15, 15, 2) if kind != 1 else np.zeros(2))      # kind 1: returns to the start
+    q = np.column_stack([np.linspace(start[0], end[0], N + 1)[1:-1] + rng.uniform(-3, 3, N - 1),
+                         np.linspace(start[1], end[1], N + 1)[1:-1] + rng.uniform(-3, 3, N - 1),
+                         rng.uniform(-2.5, 2.5, N - 1) if kind != 2 else np.zeros(N - 1)]) if N > 1 else np.zeros((0, 3))
+    hs = np.zeros((3, 3)); ts = np.zeros((3, 3))
+    hs[:2, 0] = start; ts[:2, 0] = end
+    hs[2, 0] = rng.uniform(-3, 3); ts[2, 0] = rng.uniform(-3, 3)
+    if kind == 3:                                                              # moving boundary states
+        hs[:2, 1] = rng.uniform(-2, 2, 2); ts[:2, 1] = rng.uniform(-2, 2, 2)
+    coeffs = svsdf_amd.minco_coeffs(hs, ts, q, T)
+    P = 400
+    anchors = np.vstack([start[None, :], q[:, :2], end[None, :]])
+    pts = np.zeros((P, 3))
+    pts[:, :2] = anchors[rng.integers(0, len(anchors), P)] + rng.normal(0, 2.5, (P, 2))
+    if os.environ.get("FUZZ_DEGENERATE", "1") != "0":
+        pts[:5, :2] = anchors[rng.integers(0, len(anchors), 5)]                # points exactly on waypoints (zero level set of some shapes)
+    sh = float(rng.uniform(0.2, 1.5))
+    kw = dict(safety_hor=sh, weight_p=60.0, rho=3.8, poly_params=pp, polygon=poly, head_state=hs, tail_state=ts)
+    ctx = svsdf_amd.SvsdfContext(shape=shape, device=0, **kw)
+    ctx.set_points(pts)
+    o = orc.Oracle(shape, **kw)
+    o.set_traj(coeffs, T)
+    try:
+        cost, gT, gC = ctx.eval_penalty(coeffs, T)
+        sdf, tstar, g, _ = ctx.query_points(coeffs, T)
+    except Exception as ex:
+        print("CASE", case, shape, "HIP error:", ex); bad += 1; continue
+    ocost, ogT, ogC, osdf, ots, _ = o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True)
+    rel = lambda a, b: float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300))
+    flips = float((np.abs(tstar - ots) > 1e-6).mean())
+    rc = abs(cost - ocost) / max(abs(ocost), 1e-300) if ocost != 0 else abs(cost)
+    rC, rT = (rel(gC, ogC), rel(gT, ogT)) if ocost != 0 else (float(np.abs(gC).max()), float(np.abs(gT).max()))
+    worst["cost"] = max(worst["cost"], rc); worst["gC"] = max(worst["gC"], rC); worst["gT"] = max(worst["gT"], rT)
+    worst["flips"] = max(worst["flips"], flips)
+    if rc > 1e-7 or rC > 1e-5 or rT > 1e-5 or flips > 0.01 or not np.isfinite(cost):
+        bad += 1
+        print(f"CASE {case} seed {seed0} shape {shape} pp {np.round(pp, 3)} N {N} kind {kind} sh {sh:.3f}: cost {cost:.9g} vs {ocost:.9g} "
+              f"(rel {rc:.2e}) gC {rC:.2e} gT {rT:.2e} flips {flips:.3f} interior {int((osdf <= 0).sum())}", flush=True)
+    ctx.close()
+print(f"{ncase} cases, {bad} outside the gates, worst {worst}, {time.time() - t00:.1f} s")
