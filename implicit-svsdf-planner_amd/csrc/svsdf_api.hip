@@ -68,7 +68,7 @@ struct svsdf_ctx {
   bool adaptive_iters = true;
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
-  int G_env = 0;
+  int G_env = 0, G_late_env = 0;
   double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
   // per-point / per-sub-query buffers
@@ -212,6 +212,7 @@ void launch_solve_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, l
     case 2: launch_solve_sg<S, 2, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
     case 8: launch_solve_sg<S, 8, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
     case 16: launch_solve_sg<S, 16, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
+    case 32: launch_solve_sg<S, 32, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
     default: launch_solve_sg<S, 4, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
   }
 }
@@ -611,9 +612,14 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;  // multi-stream batches (SVSDF_BATCHES) measured inconsistent across boxes
   nb = std::max(1, std::min(nb, kMaxBatches));
   ctx->nbatch = nb;
-  // lanes per query: 8 keeps the dependent chains short while a shard cannot fill the GPU anyway;
-  // 4 wastes fewer lanes once throughput matters (measured crossover ~3e5 points)
-  if (!ctx->G_env) ctx->G = (Ps < 300000) ? 8 : 4;
+  // lanes per query: an evaluation is a chain of ~10 dependent solve launches, each a chain of ~100 dependent
+  // group steps.  Small shards cannot fill the GPU and are pure latency: wide groups shorten the chains
+  // (32 lanes: a whole halving ladder / scan layer per step).  Large shards are throughput: narrow groups waste
+  // fewer lanes.  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
+  if (!ctx->G_env) {
+    ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
+    if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
+  }
   std::vector<BatchCtl> hc(kMaxBatches);
   std::memset(hc.data(), 0, sizeof(BatchCtl) * kMaxBatches);
   for (int b = 0; b < nb; ++b) {
@@ -725,8 +731,8 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     ctx->cfg.polygon_nverts = sp.nverts;
   }
   ctx->G_env = 0;
-  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
-  if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ctx->G_late = g; }
+  if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
+  if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_late = g; ctx->G_late_env = g; } }
   if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));

@@ -366,7 +366,7 @@ __device__ __forceinline__ bool qs_slot(const QuerySet &qs, int n, long long q, 
 // G lanes cooperate on one query (64/G queries per wave).
 template <int G>
 struct Grp {
-  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group size");
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32, "group size");
   __device__ static __forceinline__ int li() { return (int)(threadIdx.x & (G - 1)); }
   __device__ static __forceinline__ double bcast(double v, int src) {
     if constexpr (G == 1) return v; else return __shfl(v, src, G);

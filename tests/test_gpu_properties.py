@@ -54,7 +54,9 @@ def test_c2_full_size_solver_variants_bit_identical(c2):
     assert st_ref["scan_evals"] == st_ref["solves"] * 267          # K = floor(40 / 0.15) + 1
     for env in (dict(SVSDF_G=4, SVSDF_G_LATE=8, SVSDF_PRUNE=1, SVSDF_BATCHES=1),
                 dict(SVSDF_G=2, SVSDF_G_LATE=2, SVSDF_PRUNE=1, SVSDF_BATCHES=4),
-                dict(SVSDF_G=8, SVSDF_G_LATE=8, SVSDF_PRUNE=1, SVSDF_BATCHES=3)):
+                dict(SVSDF_G=8, SVSDF_G_LATE=8, SVSDF_PRUNE=1, SVSDF_BATCHES=3),
+                dict(SVSDF_G=16, SVSDF_G_LATE=32, SVSDF_PRUNE=1, SVSDF_BATCHES=1),
+                dict(SVSDF_G=32, SVSDF_G_LATE=16, SVSDF_PRUNE=1, SVSDF_BATCHES=2)):
         out, st = run(env)
         for a, b in zip(out, ref):
             assert np.array_equal(a, b), env
