@@ -69,6 +69,9 @@ struct svsdf_ctx {
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
   int G_env = 0, G_late_env = 0;
+  long long prev_nsolve[kMaxIter] = {};  // solves per GSIP iteration of the previous evaluation (same point set)
+  bool have_prev_nsolve = false;
+  long long wide32_below = 2000, wide16_below = 5000;  // env SVSDF_WIDE32 / SVSDF_WIDE16
   double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
   // per-point / per-sub-query buffers
@@ -108,7 +111,7 @@ struct svsdf_ctx {
 namespace {
 
 constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 9;
+constexpr size_t kOutDoubles = kOutPartial + 9 + kMaxIter;
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -380,7 +383,16 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
     QuerySet q{};
     q.qx = ctx->gs.sqx; q.qy = ctx->gs.sqy; q.count_ptr = &ctl->n_solve[it];
     q.slots = ctx->gs.solve + (size_t)ctx->bstart[b] * kMaxSlots; q.n_outer = 1;
-    const int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
+    int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
+    // Successive callbacks of one optimisation see almost the same trajectory: iteration `it` of the previous
+    // evaluation tells how many solves this launch will hold.  Few solves = a latency-bound launch (<= ~1 wave per
+    // SIMD at 32 / 16 lanes per solve): widen the groups to shorten the dependent chain.  Any width gives the
+    // same bits, so a wrong guess only costs time.
+    if (!ctx->G_env && !ctx->G_late_env && ctx->have_prev_nsolve && ctx->nbatch == 1) {
+      const long long n = ctx->prev_nsolve[it];
+      if (n < ctx->wide32_below) G = std::max(G, 32);
+      else if (n < ctx->wide16_below) G = std::max(G, 16);
+    }
     launch_solve(ctx, G, st, q, (long long)ctx->bcount[b] * kMaxSlots, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl, it + 1);
     launch_round(ctx, st, b, it + 1);
   }
@@ -472,6 +484,8 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.gsip_samples = st[6];
   ctx->stats.gsip_iterations = (unsigned)st[7];
   ctx->stats.culled_points = st[8];
+  for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
+  ctx->have_prev_nsolve = true;
   // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
   // covers an underestimate
   if (ctx->adaptive_iters) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
@@ -616,6 +630,7 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   // group steps.  Small shards cannot fill the GPU and are pure latency: wide groups shorten the chains
   // (32 lanes: a whole halving ladder / scan layer per step).  Large shards are throughput: narrow groups waste
   // fewer lanes.  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
+  ctx->have_prev_nsolve = false;
   if (!ctx->G_env) {
     ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
@@ -744,6 +759,8 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
+  if (const char *e = std::getenv("SVSDF_WIDE32")) ctx->wide32_below = std::atoll(e);
+  if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
   for (int b = 0; b < kMaxBatches; ++b) {
     if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||

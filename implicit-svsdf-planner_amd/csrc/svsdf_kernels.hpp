@@ -1107,6 +1107,11 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
     }
     stats_out[0] = so; stats_out[1] = ev; stats_out[2] = sc; stats_out[3] = in; stats_out[4] = nf;
     stats_out[5] = rem; stats_out[6] = seeded; stats_out[7] = iters; stats_out[8] = cu;
+    for (int i = 0; i < kMaxIter; ++i) {   // solves per GSIP iteration: the host sizes the next evaluation's lane groups
+      unsigned long long ns = 0;
+      for (int b = 0; b < nbatch; ++b) ns += (unsigned long long)ctl[b].n_solve[i];
+      stats_out[9 + i] = ns;
+    }
   }
 }
 
