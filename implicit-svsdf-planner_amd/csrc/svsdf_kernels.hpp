@@ -371,16 +371,45 @@ struct Grp {
   __device__ static __forceinline__ double bcast(double v, int src) {
     if constexpr (G == 1) return v; else return __shfl(v, src, G);
   }
+  // Exchange partner `step` of the butterfly over the group (step 0 .. log2(G) - 1).  Within 16 lanes the
+  // partners come through DPP (a VALU operand modifier, no LDS round trip): xor 1 and xor 2 as quad
+  // permutations, then the mirror of the 8-lane half (lane i <-> 7 - i) and of the 16-lane row (i <-> 15 - i),
+  // which pair lanes of different quads / halves just like xor 4 / xor 8 would; the 32-lane step is a shuffle.
+  template <int STEP>
+  __device__ static __forceinline__ int xchg(int v) {
+    if constexpr (STEP == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    else if constexpr (STEP == 3) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);  // row_mirror
+    else return __shfl_xor(v, 16, 32);
+  }
+  template <int STEP>
+  __device__ static __forceinline__ double xchg(double v) {
+    const int lo = xchg<STEP>(__double2loint(v)), hi = xchg<STEP>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+  // min over the group; all lanes get the result
+  __device__ static __forceinline__ int min_i(int v) {
+    if constexpr (G >= 2) v = min(v, xchg<0>(v));
+    if constexpr (G >= 4) v = min(v, xchg<1>(v));
+    if constexpr (G >= 8) v = min(v, xchg<2>(v));
+    if constexpr (G >= 16) v = min(v, xchg<3>(v));
+    if constexpr (G >= 32) v = min(v, xchg<4>(v));
+    return v;
+  }
+  template <int STEP>
+  __device__ static __forceinline__ void min_dk_step(double &d, int &k) {
+    const double od = xchg<STEP>(d);
+    const int ok = xchg<STEP>(k);
+    if (od < d || (od == d && ok < k)) { d = od; k = ok; }
+  }
   // lexicographic min of (d, k) over the group; all lanes get the result
   __device__ static __forceinline__ void min_dk(double &d, int &k) {
-    if constexpr (G > 1) {
-#pragma unroll
-      for (int m = G / 2; m >= 1; m >>= 1) {
-        const double od = __shfl_xor(d, m, G);
-        const int ok = __shfl_xor(k, m, G);
-        if (od < d || (od == d && ok < k)) { d = od; k = ok; }
-      }
-    }
+    if constexpr (G >= 2) min_dk_step<0>(d, k);
+    if constexpr (G >= 4) min_dk_step<1>(d, k);
+    if constexpr (G >= 8) min_dk_step<2>(d, k);
+    if constexpr (G >= 16) min_dk_step<3>(d, k);
+    if constexpr (G >= 32) min_dk_step<4>(d, k);
   }
   // bit i set <=> lane i of this group has pred
   __device__ static __forceinline__ unsigned ballot(bool pred) {
@@ -496,10 +525,11 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
         lbc_loc = dmin(lbc_loc, lb - ch.slack);
       }
       Grp<G>::min_dk(lb_loc, c_loc);
-      if constexpr (G > 1) {
-#pragma unroll
-        for (int m = G / 2; m >= 1; m >>= 1) lbc_loc = dmin(lbc_loc, __shfl_xor(lbc_loc, m, G));
-      }
+      if constexpr (G >= 2) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<0>(lbc_loc));
+      if constexpr (G >= 4) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<1>(lbc_loc));
+      if constexpr (G >= 8) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<2>(lbc_loc));
+      if constexpr (G >= 16) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<3>(lbc_loc));
+      if constexpr (G >= 32) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<4>(lbc_loc));
       // exact cull (main points only; cull_thresh = +inf otherwise): every pose of the continuous path keeps
       // sdf >= lbc_loc > safety_hor (upload_traj), so smoothedL1 is inactive (BEO:316-340, x < 0) whatever
       // local minimum the reference's search would return: the point contributes exactly zero
@@ -635,11 +665,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 #pragma unroll
         for (int u = U - 1; u >= 0; --u)
           if ((fc[u] - fx) < 0) { jacc = li + G * u; xa = xc[u]; fa = fc[u]; }
-        int jbest = jacc;
-        if constexpr (G > 1) {
-#pragma unroll
-          for (int m = G / 2; m >= 1; m >>= 1) jbest = min(jbest, __shfl_xor(jbest, m, G));
-        }
+        const int jbest = Grp<G>::min_i(jacc);
         if (jbest != 0x7fffffff) {
           const int src = jbest % G;
           x = Grp<G>::bcast((jacc == jbest) ? xa : 0.0, src);
@@ -855,11 +881,15 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
           g_mine[ps] = (j < n) ? gs.sq_sdf[(size_t)j * stride + ia] : kUnsolved;
           if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
         }
-#pragma unroll
-        for (int m = LP / 2; m >= 1; m >>= 1) {
-          const double og = __shfl_xor(g, m, LP);
-          const int oi = __shfl_xor(idx, m, LP);
-          if (og > g || (og == g && oi < idx)) { g = og; idx = oi; }
+        {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
+          auto step = [&](double og, int oi) { if (og > g || (og == g && oi < idx)) { g = og; idx = oi; } };
+          step(Grp<LP>::template xchg<0>(g), Grp<LP>::template xchg<0>(idx));
+          step(Grp<LP>::template xchg<1>(g), Grp<LP>::template xchg<1>(idx));
+          step(Grp<LP>::template xchg<2>(g), Grp<LP>::template xchg<2>(idx));
+          if constexpr (LP == 32) {
+            step(Grp<LP>::template xchg<3>(g), Grp<LP>::template xchg<3>(idx));
+            step(Grp<LP>::template xchg<4>(g), Grp<LP>::template xchg<4>(idx));
+          }
         }
         double max_g = -100000, real_t = res_t[i], star_th = 0.0;
         if (g > max_g) {
@@ -941,8 +971,13 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
             for (int q = 0; q < LP; ++q) theta += theta_res;
           }
         }
-#pragma unroll
-        for (int m = LP / 2; m >= 1; m >>= 1) umax = fmax(umax, __shfl_xor(umax, m, LP));
+        umax = fmax(umax, Grp<LP>::template xchg<0>(umax));
+        umax = fmax(umax, Grp<LP>::template xchg<1>(umax));
+        umax = fmax(umax, Grp<LP>::template xchg<2>(umax));
+        if constexpr (LP == 32) {
+          umax = fmax(umax, Grp<LP>::template xchg<3>(umax));
+          umax = fmax(umax, Grp<LP>::template xchg<4>(umax));
+        }
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
           list_me[ps] = valid[ps] && ub[ps] >= umax - delta;
