@@ -59,6 +59,7 @@ def lib():
     L.orc_query.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _dp, _dp]
     L.orc_penalty.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.orc_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
     L.orc_cost_function.restype = C.c_double
     L.orc_cost_function.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _dp, C.c_int, _dp]
     L.orc_minco_coeffs.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _dp]
@@ -187,6 +188,10 @@ class Oracle:
         n = self.L.orc_shape_kernels(self.ctx, ks, K, float(resolution), float(safemargin),
                                      m.ctypes.data_as(u8), b.ctypes.data_as(u8), _p(yaws))
         return m.astype(bool), b, yaws, n
+
+    def set_trig_mode(self, mode):
+        """1: sin/cos/atan2 by the ROCm device library's algorithms (diagnostic); 0: libm (oracle of record)."""
+        self.L.orc_set_trig_mode(self.ctx, int(mode))
 
     def counters(self):
         c = Counters()

@@ -24,6 +24,7 @@ struct orc_ctx {
   double head[9], tail[9]; /* 3x3 column-major: col0 = pos, col1 = vel, col2 = acc */
   orc_counters cnt;
   int have_duration;
+  int trig_mode; /* 0: libm sin/cos/atan2 (the reference's arithmetic); 1: the ROCm device library's algorithms */
 };
 
 /* thread-local work counters, folded into ctx->cnt by the entry points */
@@ -415,6 +416,16 @@ void orc_shape_grad(const orc_shape *s, double x, double y, double g[2]) {
 static inline int traj_locate(const orc_traj *tr, double *t) {
   int N = tr->N, idx;
   double dur;
+  if (tr->cum_locate) {
+    /* diagnostic "device arithmetic" mode (orc_set_trig_mode): the HIP kernels locate the piece on cumulative
+     * start times S_i = T_0 + ... + T_{i-1} (summed left to right) and take s = t - S_i, one rounding instead of
+     * the i roundings of the loop below.  Same result whenever the partial sums are exact (e.g. the equal 2.5 s
+     * pieces of every BASELINE config), otherwise within i ulp(t) of it. */
+    double S = 0.0;
+    for (idx = 0; idx < N - 1 && *t > S + tr->T[idx]; idx++) S += tr->T[idx];
+    *t = *t - S;
+    return idx;
+  }
   for (idx = 0; idx < N && *t > (dur = tr->T[idx]); idx++) *t -= dur;
   if (idx == N) { idx--; *t += tr->T[idx]; }
   return idx;
@@ -457,6 +468,111 @@ void orc_traj_pos(const orc_ctx *ctx, double t, double out[3]) { traj_pos(&ctx->
 void orc_traj_vel(const orc_ctx *ctx, double t, double out[3]) { traj_vel(&ctx->traj, t, out); }
 double orc_traj_duration(const orc_ctx *ctx) { return ctx->traj.traj_duration; }
 
+/* ---- optional "device trig" mode (diagnostic) ------------------------------------------------
+ * The reference's run-time transcendentals on this path are sin/cos of the yaw and of the GSIP
+ * sample angles and one atan2 (SWM:95); every other operation is IEEE (+, -, *, /, sqrt, compare).
+ * glibc and the ROCm device library both stay below 1 ulp but do not round identically, which is
+ * the ONLY reason the HIP path and this oracle differ in the last bits (and, on flat stretches of
+ * SDF(t), in t*).  trig_mode = 1 evaluates these three functions with the device library's published
+ * algorithms (ROCm 7.2 ocml: __ocml_sincos_f64 small-argument path = trigredsmall + sincosred2,
+ * __ocml_atan2_f64 = atanred on min/max with quadrant fix-up), written in C with exact fma(); the
+ * HIP path must then agree bit for bit per point (tests/test_gpu_parity.py).  Mode 0 is the oracle
+ * of record. */
+static void dev_sincos(double a, double *sn, double *cs) {
+  const double ax = fabs(a);
+  if (!(ax < 0x1p30)) { *sn = sin(a); *cs = cos(a); return; }
+  const double r = rint(ax * 0x1.45f306dc9c883p-1);
+  const double t4 = fma(r, -0x1.921fb54442d18p+0, ax);
+  const double t5 = fma(r, -0x1.1a62633145c00p-54, t4);
+  const double t6 = r * 0x1.1a62633145c00p-54;
+  const double t8 = fma(r, 0x1.1a62633145c00p-54, -t6);
+  const double t9 = t4 - t6;
+  const double t10 = t4 - t9;
+  const double t11 = t10 - t6;
+  const double t12 = t9 - t5;
+  const double t13 = t12 + t11;
+  const double t14 = t13 - t8;
+  const double t15 = fma(r, -0x1.b839a252049c0p-104, t14);
+  const double x = t5 + t15;
+  const double y = t15 - (x - t5);
+  const int q = (int)r & 3;
+  const double s = x * x;
+  const double h = s * 0.5;
+  const double u5 = 1.0 - h;
+  const double u7 = (1.0 - u5) - h;
+  const double s2 = s * s;
+  double pc = fma(s, -0x1.907db46cc5e42p-37, 0x1.1eeb69037ab78p-29);
+  pc = fma(s, pc, -0x1.27e4fa17f65f6p-22);
+  pc = fma(s, pc, 0x1.a01a019f4ec90p-16);
+  pc = fma(s, pc, -0x1.6c16c16c16967p-10);
+  pc = fma(s, pc, 0x1.5555555555555p-5);
+  const double ny = -y;
+  const double c15 = fma(x, ny, u7);
+  const double c16 = fma(s2, pc, c15);
+  const double cv = u5 + c16;
+  double ps = fma(s, 0x1.5e0b2f9a43bb8p-33, -0x1.ae600b42fdfa7p-26);
+  ps = fma(s, ps, 0x1.71de3796cde01p-19);
+  ps = fma(s, ps, -0x1.a01a019e83e5cp-13);
+  ps = fma(s, ps, 0x1.1111111110bb3p-7);
+  const double xs = x * (-s);
+  const double s25 = fma(xs, ps, y * 0.5);
+  const double s26 = fma(s, s25, ny);
+  const double s27 = fma(xs, -0x1.5555555555555p-3, s26);
+  const double sv = x - s27;
+  double so = (q & 1) ? cv : sv;
+  double co = (q & 1) ? -sv : cv;
+  if (q > 1) { so = -so; co = -co; }
+  if (signbit(a)) so = -so;
+  *sn = so; *cs = co;
+}
+static double dev_atan2(double y, double x) {
+  const double ay = fabs(y), ax = fabs(x);
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+  const double v = mn / mx;
+  /* __ocmlpriv_atanred_f64 */
+  const double s = v * v;
+  double p = fma(s, 0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13);
+  p = fma(s, p, 0x1.b2bb069efb384p-11);
+  p = fma(s, p, -0x1.7952daf56de9bp-9);
+  p = fma(s, p, 0x1.d6d43a595c56fp-8);
+  p = fma(s, p, -0x1.c6ea4a57d9582p-7);
+  p = fma(s, p, 0x1.67e295f08b19fp-6);
+  p = fma(s, p, -0x1.e9ae6fc27006ap-6);
+  p = fma(s, p, 0x1.2c15b5711927ap-5);
+  p = fma(s, p, -0x1.59976e82d3ff0p-5);
+  p = fma(s, p, 0x1.82d5d6ef28734p-5);
+  p = fma(s, p, -0x1.ae5ce6a214619p-5);
+  p = fma(s, p, 0x1.e1bb48427b883p-5);
+  p = fma(s, p, -0x1.110e48b207f05p-4);
+  p = fma(s, p, 0x1.3b13657b87036p-4);
+  p = fma(s, p, -0x1.745d119378e4fp-4);
+  p = fma(s, p, 0x1.c71c717e1913cp-4);
+  p = fma(s, p, -0x1.2492492376b7dp-3);
+  p = fma(s, p, 0x1.99999999952ccp-3);
+  p = fma(s, p, -0x1.5555555555523p-2);
+  const double a0 = fma(v, s * p, v);
+  /* quadrant fix-up of __ocml_atan2_f64 */
+  const double pio2 = 0x1.921fb54442d18p+0, pi = 0x1.921fb54442d18p+1;
+  const int xneg = signbit(x) ? 1 : 0;
+  double t = (ax < ay) ? (pio2 - a0) : a0;
+  t = xneg ? (pi - t) : t;
+  if (y == 0.0) t = xneg ? pi : 0.0;
+  if (isinf(ax) && isinf(ay)) t = xneg ? 0x1.2d97c7f3321d2p+1 : 0x1.921fb54442d18p-1;
+  if (isnan(x) || isnan(y)) t = NAN;
+  return copysign(t, y);
+}
+static inline void trig_sincos(const orc_ctx *ctx, double a, double *sn, double *cs) {
+  if (ctx->trig_mode) dev_sincos(a, sn, cs);
+  else { *sn = sin(a); *cs = cos(a); }
+}
+static inline double trig_atan2(const orc_ctx *ctx, double y, double x) {
+  return ctx->trig_mode ? dev_atan2(y, x) : atan2(y, x);
+}
+void orc_set_trig_mode(orc_ctx *ctx, int mode) {
+  ctx->trig_mode = mode ? 1 : 0;
+  ctx->traj.cum_locate = ctx->trig_mode;
+}
+
 /* ------------------------------------------------------------------------- */
 /* SDF at a time stamp, argmin over t                                         */
 /* ------------------------------------------------------------------------- */
@@ -466,7 +582,8 @@ static inline double sdf_at_time(const orc_ctx *ctx, double px, double py, doubl
   double xt[3];
   traj_pos(&ctx->traj, t, xt);
   double yaw = xt[2];
-  double s = sin(yaw), c = cos(yaw);
+  double s, c;
+  trig_sincos(ctx, yaw, &s, &c);
   double dx = px - xt[0], dy = py - xt[1];
   double rx = c * dx + s * dy;
   double ry = (-s) * dx + c * dy;
@@ -483,7 +600,8 @@ static inline void grad_prel_at_time(const orc_ctx *ctx, double px, double py, d
   double xt[3];
   traj_pos(&ctx->traj, t, xt);
   double yaw = xt[2];
-  double s = sin(yaw), c = cos(yaw);
+  double s, c;
+  trig_sincos(ctx, yaw, &s, &c);
   double dx = px - xt[0], dy = py - xt[1];
   double rx = c * dx + s * dy;
   double ry = (-s) * dx + c * dy;
@@ -616,7 +734,7 @@ static double true_sdf(const orc_ctx *ctx, double px, double py, double *time_se
 #undef VNORM
   /* SampleSet2D::initSet SWM:73-103 */
   double cxr = px, cyr = py, r = r0;
-  double theta0 = atan2(vel[0], -vel[1]);
+  double theta0 = trig_atan2(ctx, vel[0], -vel[1]);
   if (theta0 < 0) theta0 += 2 * ORC_PI;
   double theta_res = ORC_PI + 0.1, rk_res = 1.5, rk0 = 1.0;
 
@@ -629,8 +747,10 @@ static double true_sdf(const orc_ctx *ctx, double px, double py, double *time_se
     int Y_size = sample_elements(theta0, theta_res, rk0, rk_res, el_rk, el_th);
     for (int i = 0; i < Y_size; i++) {
       /* CircleCoord2D::getPosition SWM:36-39 */
-      double ykx = cxr + el_rk[i] * r * cos(el_th[i]);
-      double yky = cyr + el_rk[i] * r * sin(el_th[i]);
+      double sth, cth;
+      trig_sincos(ctx, el_th[i], &sth, &cth);
+      double ykx = cxr + el_rk[i] * r * cth;
+      double yky = cyr + el_rk[i] * r * sth;
       cur_g = sdf_swept(ctx, ykx, yky, time_seed_f, grad_prel);
       if (cur_g > max_g) {
         max_g = cur_g;
@@ -649,8 +769,10 @@ static double true_sdf(const orc_ctx *ctx, double px, double py, double *time_se
     theta0 = star_th;
     iter++;
   }
-  double corx = cxr + star_rk * r_star * cos(star_th);
-  double cory = cyr + star_rk * r_star * sin(star_th);
+  double sst, cst;
+  trig_sincos(ctx, star_th, &sst, &cst);
+  double corx = cxr + star_rk * r_star * cst;
+  double cory = cyr + star_rk * r_star * sst;
   double gx = corx - px, gy = cory - py;
   double z = gx * gx + gy * gy; /* normalize(): divide iff squaredNorm > 0 */
   if (z > 0.0) { double n = sqrt(z); gx = gx / n; gy = gy / n; }
@@ -707,7 +829,8 @@ static void point_contribution(const orc_ctx *ctx, double px, double py, point_c
     pos[d] = a; vel[d] = b;
   }
   double yaw = pos[2];
-  double sy = sin(yaw), cy = cos(yaw); /* rotate = AngleAxisd(yaw, Z) */
+  double sy, cy; /* rotate = AngleAxisd(yaw, Z) */
+  trig_sincos(ctx, yaw, &sy, &cy);
   pos[2] = 0.0;
   if (sdf_value < 0) { /* BEO:832: gradp_rel = rotate^T * gradp_rel */
     double gx = cy * gradp_rel[0] + sy * gradp_rel[1];
@@ -727,8 +850,8 @@ static void point_contribution(const orc_ctx *ctx, double px, double py, point_c
     gradp[0] += sgx; gradp[1] += sgy;
     double dx = px - pos[0], dy = py - pos[1];
     /* VR_theta^T * p_minus_x, VR_theta = [[-s,-c,0],[c,-s,0],[0,0,1]] */
-    double v0 = (-sin(yaw)) * dx + (cos(yaw)) * dy;
-    double v1 = (-cos(yaw)) * dx + (-sin(yaw)) * dy;
+    double v0 = (-sy) * dx + (cy) * dy;
+    double v1 = (-cy) * dx + (-sy) * dy;
     grad_yaw = (-sdf_out_grad * gradp_rel[0]) * v0 + (-sdf_out_grad * gradp_rel[1]) * v1;
   }
   double gPx = 0.0, gPy = 0.0, gYaw = 0.0, pena = 0.0;

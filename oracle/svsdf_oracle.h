@@ -19,6 +19,8 @@
  * second restatement whose outputs are committed as golden vectors
  * (tests/golden/make_golden.py -> tests/golden/golden_small.json) and (iv)
  * finite-difference checks of the assembled gradient.  See DESIGN.md "Oracle".
+ * orc_set_trig_mode(ctx, 1) is a diagnostic variant (device-library trig, cumulative piece times) in which
+ * the HIP path must match bit for bit; mode 0 is the oracle of record.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library.  The product path (implicit-svsdf-planner_amd/csrc) never links,
@@ -75,6 +77,7 @@ typedef struct orc_traj {
   double *T;              /* N durations */
   double *c;              /* per piece: c[(i*6 + k)*3 + d] = coefficient of s^k, dim d */
   double traj_duration;   /* SWM:376-385 (only updated when total < 300 s) */
+  int cum_locate;         /* diagnostic device-arithmetic mode: piece local time as t - S_i (see traj_locate) */
 } orc_traj;
 
 /* Work counters (per call of orc_penalty / orc_query; summed over threads). */
@@ -131,6 +134,11 @@ void orc_penalty(orc_ctx *ctx, const double *xyz, size_t P, int nthreads, int su
                  double *sdf, double *tstar, double *pcost);
 
 void orc_get_counters(const orc_ctx *ctx, orc_counters *out);
+/* Diagnostic "device arithmetic" mode: evaluate the path's run-time sin/cos/atan2 with the ROCm device library's
+ * algorithms instead of libm, and the local time of piece i as t - (T_0 + ... + T_{i-1}) instead of i successive
+ * subtractions (see svsdf_oracle.c) -- the two places where the HIP kernels' arithmetic is not the reference's
+ * operation for operation.  Mode 0 (default) is the oracle of record. */
+void orc_set_trig_mode(orc_ctx *ctx, int mode);
 
 /* ---- MINCO S3NU + full callback (a14) --------------------------------------- */
 /* x = [tau_0..tau_{N-1}, q_0 (x,y,yaw), ..., q_{N-2}], n = N + 3(N-1). Returns cost,

@@ -209,3 +209,39 @@ def test_differential_fuzz(built):
     worst = ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1])
     assert "HIP error" not in out, out[-2000:]
     assert worst["cost"] <= 1e-7 and worst["gC"] <= 1e-4 and worst["gT"] <= 1e-4, last
+
+
+@pytest.mark.parametrize("config,P", [("C1", 6000), ("C2", 6000), ("C3", 4000), ("C4", 4000), ("C5", 3000)])
+def test_bit_identical_when_oracle_uses_device_trig(built, config, P):
+    """The HIP kernels' arithmetic differs from the reference's, operation for operation, in exactly two places:
+    (a) sin/cos (pose yaw, GSIP sample angles) and the one atan2 come from the ROCm device library instead of
+    glibc, (b) the local time of piece i is t - (T_0 + ... + T_{i-1}) instead of i successive subtractions
+    (TRJ:498-516; no difference for the equal 2.5 s pieces of the BASELINE configs).  With the oracle switched to
+    the same two choices (orc_set_trig_mode(1): the device library's published algorithms written in C) the HIP
+    pipeline -- pose table, exact pruning, lane groups, upper-bound sample selection, cull, all of it -- must
+    reproduce the oracle's per-point SVSDF, t* and gradient direction BIT FOR BIT."""
+    w, ctx, o = _mk(config, P)
+    o.set_trig_mode(1)
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    osdf, ots, og = o.query(w["points"], nthreads=NT)
+    same_t = ts == ots
+    same_s = sdf == osdf
+    same_g = (g == og).all(axis=1)
+    print(f"{config}: identical t* {same_t.mean():.5f}  sdf {same_s.mean():.5f}  grad {same_g.mean():.5f} of {P}")
+    assert same_t.all() and same_s.all() and same_g.all()
+
+
+def test_differential_fuzz_bit_identical_in_device_arithmetic_mode(built):
+    """Same random cases as test_differential_fuzz (all 17 shapes, shape offsets, 1-6 unequal pieces), this time WITH
+    the degenerate points (exactly on waypoints = on the zero level set of some shapes at a rest pose) and with the
+    oracle in device-arithmetic mode: not one of the per-point (t*, SVSDF) values may differ in any bit, and cost /
+    gradients agree to summation order (1e-12)."""
+    import ast, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_DEGENERATE="1", FUZZ_DEVICE_TRIG="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "11"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode()
+    last = out.strip().splitlines()[-1]
+    worst = ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1])
+    assert worst["not_identical"] == 0, out[-3000:]
+    assert worst["cost"] <= 1e-12 and worst["gC"] <= 1e-12 and worst["gT"] <= 1e-12 and worst["flips"] == 0.0, last

@@ -48,6 +48,9 @@ for case in range(ncase):
     ctx.set_points(pts)
     o = orc.Oracle(shape, **kw)
     o.set_traj(coeffs, T)
+    devtrig = os.environ.get("FUZZ_DEVICE_TRIG", "0") == "1"   # oracle in device-arithmetic mode (orc_set_trig_mode)
+    if devtrig:
+        o.set_trig_mode(1)
     try:
         cost, gT, gC = ctx.eval_penalty(coeffs, T)
         sdf, tstar, g, _ = ctx.query_points(coeffs, T)
@@ -56,6 +59,11 @@ for case in range(ncase):
     ocost, ogT, ogC, osdf, ots, _ = o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True)
     rel = lambda a, b: float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300))
     flips = float((np.abs(tstar - ots) > 1e-6).mean())
+    if devtrig:
+        nd = int((tstar != ots).sum() + (sdf != osdf).sum())
+        worst["not_identical"] = worst.get("not_identical", 0) + nd
+        if nd:
+            print(f"CASE {case} seed {seed0} shape {shape} pp {np.round(pp, 2)} N {N} kind {kind} dur {T.sum():.2f}: {nd} per-point values differ from the device-trig oracle (t* {int((tstar != ots).sum())}, sdf {int((sdf != osdf).sum())})", flush=True)
     rc = abs(cost - ocost) / max(abs(ocost), 1e-300) if ocost != 0 else abs(cost)
     rC, rT = (rel(gC, ogC), rel(gT, ogT)) if ocost != 0 else (float(np.abs(gC).max()), float(np.abs(gT).max()))
     worst["cost"] = max(worst["cost"], rc); worst["gC"] = max(worst["gC"], rC); worst["gT"] = max(worst["gT"], rT)
