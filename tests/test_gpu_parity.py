@@ -245,3 +245,43 @@ def test_differential_fuzz_bit_identical_in_device_arithmetic_mode(built):
     worst = ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1])
     assert worst["not_identical"] == 0, out[-3000:]
     assert worst["cost"] <= 1e-12 and worst["gC"] <= 1e-12 and worst["gT"] <= 1e-12 and worst["flips"] == 0.0, last
+
+
+def test_limits(built):
+    """Limits of the boundary: 64 pieces (kMaxPieces) work and agree with the oracle, 65 are refused; durations just
+    below and above the 300 s traj_duration gate (SWM:380-384); non-finite inputs are refused, never propagated."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    w, ctx, o = _mk("C2", 3000, N=64)
+    assert len(w["T"]) == 64
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost) and _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5
+    T65 = np.full(65, 1.0)
+    with pytest.raises(svsdf_amd.SvsdfError):
+        ctx.eval_penalty(np.zeros((6 * 65, 3)), T65)
+    # 290 s (regular regime, K = 1934 table poses) and 310 s after it (gate: the scan keeps the 290 s duration)
+    w2, ctx2, o2 = _mk("C2", 1500)
+    for scale in (7.25, 7.75):
+        T = np.asarray(w2["T"]) * scale
+        c = svsdf_amd.minco_coeffs(w2["head_state"], w2["tail_state"], w2["q"], T)
+        cost, gT, gC = ctx2.eval_penalty(c, T)
+        o2.set_traj(c, T)
+        ocost, ogT, ogC = o2.penalty(w2["points"], nthreads=NT, sum_mode=1)
+        assert abs(o2.duration() - 290.0) < 1e-9
+        assert abs(cost - ocost) <= 1e-7 * abs(ocost) and _rel(gC, ogC) <= 1e-5, (scale, cost, ocost)
+    # non-finite inputs
+    bad = w2["coeffs"].copy(); bad[3, 1] = np.nan
+    with pytest.raises(svsdf_amd.SvsdfError):
+        ctx2.eval_penalty(bad, w2["T"])
+    with pytest.raises(svsdf_amd.SvsdfError):
+        ctx2.set_points(np.array([[1.0, np.inf, 0.0]]))
+    with pytest.raises(svsdf_amd.SvsdfError):
+        ctx2.lmbm_evaluate(np.full(4 * 16 - 3, np.nan))
+    # the raw C callback (what LMBM would call) has no error channel: +inf and a zero gradient, never NaN
+    import ctypes as C
+    x = np.full(4 * 16 - 3, np.nan)
+    g = np.ones_like(x)
+    dp = C.POINTER(C.c_double)
+    f = svsdf_amd.lib().svsdf_lmbm_evaluate(ctx2.ctx, x.ctypes.data_as(dp), g.ctypes.data_as(dp), len(x))
+    assert np.isinf(f) and f > 0 and not g.any()
