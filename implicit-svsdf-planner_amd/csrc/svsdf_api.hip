@@ -71,7 +71,7 @@ struct svsdf_ctx {
   int G_env = 0, G_late_env = 0;
   long long prev_nsolve[kMaxIter] = {};  // solves per GSIP iteration of the previous evaluation (same point set)
   bool have_prev_nsolve = false;
-  long long wide32_below = 2000, wide16_below = 5000;  // env SVSDF_WIDE32 / SVSDF_WIDE16
+  long long wide32_below = 2000, wide16_below = 5000, wide8_below = 40000;  // env SVSDF_WIDE32 / SVSDF_WIDE16 / SVSDF_WIDE8
   double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
 
   // per-point / per-sub-query buffers
@@ -386,12 +386,14 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
     int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
     // Successive callbacks of one optimisation see almost the same trajectory: iteration `it` of the previous
     // evaluation tells how many solves this launch will hold.  Few solves = a latency-bound launch (<= ~1 wave per
-    // SIMD at 32 / 16 lanes per solve): widen the groups to shorten the dependent chain.  Any width gives the
-    // same bits, so a wrong guess only costs time.
+    // SIMD): widen the groups to shorten the dependent chain; many solves = throughput: keep the shard's width even
+    // in late iterations.  Any width gives the same bits, so a wrong guess only costs time.
     if (!ctx->G_env && !ctx->G_late_env && ctx->have_prev_nsolve && ctx->nbatch == 1) {
       const long long n = ctx->prev_nsolve[it];
+      G = ctx->G;
       if (n < ctx->wide32_below) G = std::max(G, 32);
       else if (n < ctx->wide16_below) G = std::max(G, 16);
+      else if (n < ctx->wide8_below) G = std::max(G, 8);
     }
     launch_solve(ctx, G, st, q, (long long)ctx->bcount[b] * kMaxSlots, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl, it + 1);
     launch_round(ctx, st, b, it + 1);
@@ -761,6 +763,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_WIDE32")) ctx->wide32_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);
+  if (const char *e = std::getenv("SVSDF_WIDE8")) ctx->wide8_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
   for (int b = 0; b < kMaxBatches; ++b) {
     if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||
