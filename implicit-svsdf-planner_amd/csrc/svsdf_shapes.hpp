@@ -238,6 +238,27 @@ __device__ __forceinline__ double sdf_arc(double px, double py, double scx, doub
 }
 
 // Polygon: SHP:1370-1401 (edge helpers) + SHP:1448-1476.  No trans/Rotate (as the reference).
+// isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
+// atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
+// opposite signs of y and the vector with y > 0 leading the other by more than pi counter-clockwise, i.e.
+// sign(cross(s2, e2)) -- decided without atan2 unless the angle difference is within ~1e-9 rad of 0 or pi
+// (sin^2 <= 1e-18), where the rounding of the two atan2 values (~1e-16) could matter and the reference
+// formula itself is evaluated.
+__device__ __forceinline__ bool poly_cross_ray(double s2x, double s2y, double e2x, double e2y) {
+  const double crs = s2x * e2y - s2y * e2x;
+  const double n2 = (s2x * s2x + s2y * s2y) * (e2x * e2x + e2y * e2y);
+  if (s2y != 0.0 && e2y != 0.0 && crs * crs > 1e-18 * n2) {
+    const bool sneg = s2y < 0.0, eneg = e2y < 0.0;
+    return (sneg != eneg) && ((crs < 0.0) == eneg);
+  }
+  double theta_s = atan2(s2y, s2x);
+  double theta_e = atan2(e2y, e2x);
+  theta_s = (theta_s < 0.0) ? (theta_s + 2 * kPI) : theta_s;
+  theta_e = (theta_e < 0.0) ? (theta_e + 2 * kPI) : theta_e;
+  return !(fabs(theta_s - theta_e) < kPI);
+}
+
+// Polygon::getonlySDF (SHP:1448-1476) with the closest point (needed by the analytic gradient SHP:1505-1531).
 __device__ inline double sdf_polygon(const ShapeParams &sp, double x, double y, double *cminx,
                                      double *cminy) {
   double dis_min = 1e9, mx = 0.0, my = 0.0;
@@ -256,27 +277,34 @@ __device__ inline double sdf_polygon(const ShapeParams &sp, double x, double y, 
     const double cx = sx + t * vx, cy = sy + t * vy;
     const double dis = norm2(x - cx, y - cy);
     if (dis < dis_min) { dis_min = dis; mx = cx; my = cy; }
-    // isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
-    // atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
-    // opposite signs of y and the vector with y > 0 leading the other by more than pi counter-clockwise, i.e.
-    // sign(cross(s2, e2)) -- decided without atan2 unless the angle difference is within ~1e-9 rad of 0 or pi
-    // (sin^2 <= 1e-18), where the rounding of the two atan2 values (~1e-16) could matter and the reference
-    // formula itself is evaluated.
-    const double s2x = sx - x, s2y = sy - y, e2x = ex - x, e2y = ey - y;
-    const double crs = s2x * e2y - s2y * e2x;
-    const double n2 = (s2x * s2x + s2y * s2y) * (e2x * e2x + e2y * e2y);
-    if (s2y != 0.0 && e2y != 0.0 && crs * crs > 1e-18 * n2) {
-      const bool sneg = s2y < 0.0, eneg = e2y < 0.0;
-      if ((sneg != eneg) && ((crs < 0.0) == eneg)) rs++;
-    } else {
-      double theta_s = atan2(s2y, s2x);
-      double theta_e = atan2(e2y, e2x);
-      theta_s = (theta_s < 0.0) ? (theta_s + 2 * kPI) : theta_s;
-      theta_e = (theta_e < 0.0) ? (theta_e + 2 * kPI) : theta_e;
-      if (!(fabs(theta_s - theta_e) < kPI)) rs++;
-    }
+    if (poly_cross_ray(sx - x, sy - y, ex - x, ey - y)) rs++;
   }
   if (cminx) { *cminx = mx; *cminy = my; }
+  return (rs % 2 == 0) ? dis_min : -dis_min;
+}
+
+// Value only (the hot path): min_i sqrt(d2_i) == sqrt(min_i d2_i) exactly -- sqrt is correctly rounded and
+// monotone and the d2_i are the same numbers norm() would square-root -- so one sqrt per evaluation instead of
+// one per edge; which edge attains the minimum (ties of rounded roots) only matters for the closest point above.
+__device__ inline double sdf_polygon_value(const ShapeParams &sp, double x, double y) {
+  double d2_min = 1e300;
+  int rs = 0;
+  const int n = sp.nverts;
+  for (int i = 0; i < n; ++i) {
+    const int j = (i + 1 == n) ? 0 : i + 1;
+    const double sx = sp.verts[2 * i], sy = sp.verts[2 * i + 1];
+    const double ex = sp.verts[2 * j], ey = sp.verts[2 * j + 1];
+    const double vx = ex - sx, vy = ey - sy;
+    const double wx = x - sx, wy = y - sy;
+    double t = (wx * vx + wy * vy) / (vx * vx + vy * vy);
+    if (t < 0.0) t = 0.0;
+    else if (t > 1.0) t = 1.0;
+    const double cx = sx + t * vx, cy = sy + t * vy;
+    const double dx = x - cx, dy = y - cy;
+    d2_min = dmin(d2_min, dx * dx + dy * dy);
+    if (poly_cross_ray(sx - x, sy - y, ex - x, ey - y)) rs++;
+  }
+  const double dis_min = dmin(sqrt(d2_min), 1e9);   // the reference's running minimum starts at 1e9
   return (rs % 2 == 0) ? dis_min : -dis_min;
 }
 
@@ -304,7 +332,7 @@ __device__ __forceinline__ double shape_core(const ShapeParams &sp, double px, d
 template <int SHAPE>
 __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, double y) {
   if constexpr (SHAPE == kPolygon) {
-    return sdf_polygon(sp, x, y, nullptr, nullptr);
+    return sdf_polygon_value(sp, x, y);
   } else {
     double px = x, py = y;
     if (!sp.identity) {  // wave-uniform; with trans = 0, Rotate = I the products below are exact no-ops
