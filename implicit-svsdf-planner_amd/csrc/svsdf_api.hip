@@ -64,7 +64,7 @@ struct svsdf_ctx {
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
-  int late_iter = 4, first_iters = 12, it_done = 0, U = 1, round_lp8_iters = 2, delta_all_iter = 5;
+  int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
@@ -72,7 +72,7 @@ struct svsdf_ctx {
   long long prev_nsolve[kMaxIter] = {};  // solves per GSIP iteration of the previous evaluation (same point set)
   bool have_prev_nsolve = false;
   long long wide32_below = 2000, wide16_below = 5000, wide8_below = 40000;  // env SVSDF_WIDE32 / SVSDF_WIDE16 / SVSDF_WIDE8
-  double select_delta = 0.1;  // k_select: solve the samples within this of the best seed bound first
+  double select_delta = 0.1;  // k_round: solve the samples whose upper bound is within this of the best one first
 
   // per-point / per-sub-query buffers
   double *d_sdf = nullptr, *d_t = nullptr;
@@ -756,7 +756,6 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
   if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) ctx->delta_all_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
-  if (const char *e = std::getenv("SVSDF_U")) ctx->U = std::atoi(e) == 2 ? 2 : 1;
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) ctx->select_delta = std::atof(e);
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);

@@ -36,7 +36,7 @@ constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
 constexpr int kBlock = 256;
 constexpr int kMaxBatches = 8;
 // GSIP iterations: a round normally takes one iteration, plus one supplementary iteration when
-// the upper-bound selection (k_select / k_gsip) has to solve more samples of the same round.
+// the upper-bound selection (k_round) has to solve more samples of the same round.
 constexpr int kMaxIter = 24;
 constexpr int kWorkCounters = kMaxIter + 2;        // one per k_solve launch of a batch
 constexpr double kUnsolved = -1e300;               // sq_sdf marker: sample not (yet) solved
