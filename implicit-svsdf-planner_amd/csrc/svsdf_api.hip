@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -66,12 +67,17 @@ struct svsdf_ctx {
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
+  bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
+  bool ub_env = false;         // env SVSDF_UB_FULL=0/1 pins the mode, otherwise run_pipeline picks the faster one
+  int ub_tune = 0;             // 0..3: timing evaluations after a new point set, 4: decided
+  double ub_ms[2] = {0.0, 0.0};
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
   int G_env = 0, G_late_env = 0;
   long long prev_nsolve[kMaxIter] = {};  // solves per GSIP iteration of the previous evaluation (same point set)
   bool have_prev_nsolve = false;
   long long wide32_below = 2000, wide16_below = 5000, wide8_below = 40000;  // env SVSDF_WIDE32 / SVSDF_WIDE16 / SVSDF_WIDE8
+  bool select_env = false, all_iter_env = false;
   double select_delta = 0.1;  // k_round: solve the samples whose upper bound is within this of the best one first
 
   // per-point / per-sub-query buffers
@@ -228,18 +234,23 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
 #undef CALL
 }
 
-void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
+template <bool FULLUB>
+void launch_round_m(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const long long pts = std::max(1, ctx->bcount[b]);
   const size_t lds = table_lds_doubles(ctx) * sizeof(double);
   // late iterations hold few points and are latency-bound: request every sample there, which
   // avoids supplementary iterations at no cost in time
-  const double delta = (it >= ctx->delta_all_iter) ? 1e300 : ctx->select_delta;
+  // the seed bound of the full-scan mode is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
+  // iteration 7); the chunk bound of the cheap mode needs 0.1 m / iteration 5.  Env values override both.
+  const double sel = (FULLUB && !ctx->select_env) ? 0.01 : ctx->select_delta;
+  const int all_it = (FULLUB && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
+  const double delta = (it >= all_it) ? 1e300 : sel;
   // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per
   // point; later rounds have 18-21 samples: 32 lanes per point (either handles any count)
   if (it < ctx->round_lp8_iters) {
     const unsigned grid = (unsigned)std::min<long long>((pts * 8 + kRoundBlock - 1) / kRoundBlock, 1024);
 #define CALL(S)                                                                                           \
-  hipLaunchKernelGGL((k_round<S, 8>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,   \
+  hipLaunchKernelGGL((k_round<S, 8, FULLUB>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,   \
                      ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, \
                      ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
     SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
@@ -247,12 +258,17 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   } else {
     const unsigned grid = (unsigned)std::min<long long>((pts * 32 + kRoundBlock - 1) / kRoundBlock, 1024);
 #define CALL(S)                                                                                           \
-  hipLaunchKernelGGL((k_round<S, 32>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,  \
+  hipLaunchKernelGGL((k_round<S, 32, FULLUB>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,  \
                      ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, \
                      ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
     SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
   }
+}
+
+void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
+  if (ctx->ub_full) launch_round_m<true>(ctx, st, b, it);
+  else launch_round_m<false>(ctx, st, b, it);
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
@@ -383,6 +399,7 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
     QuerySet q{};
     q.qx = ctx->gs.sqx; q.qy = ctx->gs.sqy; q.count_ptr = &ctl->n_solve[it];
     q.slots = ctx->gs.solve + (size_t)ctx->bstart[b] * kMaxSlots; q.n_outer = 1;
+    if (ctx->ub_full) { q.seed_k = ctx->gs.sq_k; q.seed_d = ctx->gs.sq_ub; }
     int G = (it >= ctx->late_iter) ? ctx->G_late : ctx->G;
     // Successive callbacks of one optimisation see almost the same trajectory: iteration `it` of the previous
     // evaluation tells how many solves this launch will hold.  Few solves = a latency-bound launch (<= ~1 wave per
@@ -521,9 +538,27 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
 
 // Whole device pipeline; leaves [cost, gradC, gradT] (19N+1 doubles) in d_out / h_out.
 int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  // GSIP upper-bound mode: the cheap bound (8 table poses of the nearest chunk) is enough for some shapes (star:
+  // full scans only add 15 %), useless for others (sdHorseshoe: 5.3 -> 2 solves per point, 2x overall).  Both
+  // modes give the same bits, so the choice is made by the clock: after a new point set evaluations 2 and 4 are
+  // timed (1 and 3 warm the adaptive launch plan up in the respective mode), the faster mode is kept.
+  const int phase = ctx->ub_env ? -1 : ctx->ub_tune;
+  if (phase >= 0 && phase < 4) ctx->ub_full = phase >= 2;
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/true);
   if (rc) return rc;
-  return finish(ctx, true);
+  rc = finish(ctx, true);
+  if (rc == SVSDF_OK && phase >= 0 && phase < 4) {
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (phase == 1) ctx->ub_ms[0] = ms;
+    if (phase == 3) {
+      ctx->ub_ms[1] = ms;
+      ctx->ub_full = ctx->ub_ms[1] < ctx->ub_ms[0];
+      ctx->have_prev_nsolve = ctx->ub_full;   // the launch plan on record is the full-scan one
+    }
+    ctx->ub_tune = phase + 1;
+  }
+  return rc;
 }
 
 void accumulate(int N, const double *partial, double *cost, double *gradT, double *gradC) {
@@ -557,6 +592,7 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.sqy, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqth, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_ub, S))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.sq_k, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_sdf, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_t, S))) return rc;
   return SVSDF_OK;
@@ -633,6 +669,8 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   // (32 lanes: a whole halving ladder / scan layer per step).  Large shards are throughput: narrow groups waste
   // fewer lanes.  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
   ctx->have_prev_nsolve = false;
+  ctx->ub_tune = 0;
+  if (!ctx->ub_env) ctx->ub_full = false;
   if (!ctx->G_env) {
     ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
@@ -754,12 +792,13 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
-  if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) ctx->delta_all_iter = std::atoi(e);
+  if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) { ctx->delta_all_iter = std::atoi(e); ctx->all_iter_env = true; }
   if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
-  if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) ctx->select_delta = std::atof(e);
+  if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) { ctx->select_delta = std::atof(e); ctx->select_env = true; }
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
+  if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_env = true; }
   if (const char *e = std::getenv("SVSDF_WIDE32")) ctx->wide32_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE8")) ctx->wide8_below = std::atoll(e);
@@ -804,7 +843,7 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs.pt,
                   ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.phase,
                   ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
-                  ctx->gs.sq_ub, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl, ctx->d_block_partials, ctx->d_sums,
+                  ctx->gs.sq_ub, ctx->gs.sq_k, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl, ctx->d_block_partials, ctx->d_sums,
                   ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_flag};
   for (void *p : bufs)
     if (p) (void)hipFree(p);

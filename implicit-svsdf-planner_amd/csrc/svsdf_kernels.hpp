@@ -348,6 +348,8 @@ struct QuerySet {
   int base;
   int n_outer;
   const int *slots;       // explicit slot list (n = *count_ptr entries, overrides the rest) or null
+  const int *seed_k;      // per slot: layer-1 seed already known (GSIP samples scanned by k_round), or null
+  const double *seed_d;
 };
 
 __device__ __forceinline__ long long qs_total(const QuerySet &qs, int &n) {
@@ -434,6 +436,111 @@ __device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wav
 }
 
 // ---------------------------------------------------------------------------------------------
+// choiceTInit layer 1 (SWM:549-576, first pass) for one query by G cooperating lanes, on the pose table in LDS:
+// the chunk with the smallest lower bound first, then every chunk whose bound does not exceed the running
+// minimum (exact: a skipped sample can never be, or tie with, the strict-`<` minimum).  Returns the seed
+// (best_d = min_dis, best_k = index of the earliest minimal sample); `culled` only with a finite cull_thresh.
+// ---------------------------------------------------------------------------------------------
+// LITE (GSIP samples: no cull bound needed): square-root-free chunk tests -- first chunk = nearest centre, then
+// every chunk with |q - c|^2 <= (min + rb)^2 (1 + 1e-12), a superset of the exact test, so the seed is the same.
+template <int SHAPE, int G, bool LITE = false>
+__device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *pose, const Chunk *chunks, int K,
+                                            int nch, double px, double py, int prune, double cull_thresh,
+                                            double &best_d, int &best_k, bool &culled, unsigned &n_scan) {
+  const int li = Grp<G>::li();
+  best_d = 1e9;   // min_dis initial value (SWM:545)
+  best_k = 0x7fffffff;
+  culled = false;
+  auto eval_chunk = [&](int c) {
+    double d_loc = 1e300;
+    int k_loc = 0x7fffffff;
+    constexpr int GS = (G < kChunk) ? G : kChunk;
+#pragma unroll
+    for (int m = 0; m < kChunk / GS; ++m) {
+      const int k = c * kChunk + li + GS * m;
+      if (li < kChunk && k < K) {
+        const Pose p = pose[k];
+        const double d = sdf_from_pose<SHAPE>(sp, p, px, py);
+        ++n_scan;
+        if (d < d_loc) { d_loc = d; k_loc = k; }  // k increases with m: earliest kept on ties
+      }
+    }
+    Grp<G>::min_dk(d_loc, k_loc);
+    if (d_loc < best_d || (d_loc == best_d && k_loc < best_k)) { best_d = d_loc; best_k = k_loc; }
+  };
+  if constexpr (LITE) {
+    double d2_loc = 1e300;
+    int c_loc = 0;
+    for (int c = li; c < nch; c += G) {
+      const Chunk ch = chunks[c];
+      const double ex = px - ch.cx, ey = py - ch.cy;
+      const double d2 = ex * ex + ey * ey;
+      if (d2 < d2_loc) { d2_loc = d2; c_loc = c; }
+    }
+    Grp<G>::min_dk(d2_loc, c_loc);
+    const int c0 = c_loc;
+    eval_chunk(c0);
+    int c = 0;
+    while (c < nch) {
+      const int cc = c + li;
+      bool need = false;
+      if (cc < nch && cc != c0) {
+        const Chunk ch = chunks[cc];
+        const double ex = px - ch.cx, ey = py - ch.cy;
+        const double t = best_d + ch.rb;
+        need = (t >= 0.0) && (ex * ex + ey * ey <= t * t * (1.0 + 1e-12));
+      }
+      const unsigned m = Grp<G>::ballot(need);
+      if (m == 0u) { c += G; continue; }
+      const int first = __ffs(m) - 1;
+      eval_chunk(c + first);
+      c = c + first + 1;
+    }
+  } else if (!prune) {
+    for (int c = 0; c < nch; ++c) eval_chunk(c);
+  } else {
+    // 1. the chunk with the smallest lower bound gives the first upper bound
+    double lb_loc = 1e300, lbc_loc = 1e300;
+    int c_loc = 0;
+    for (int c = li; c < nch; c += G) {
+      const Chunk ch = chunks[c];
+      const double lb = norm2(px - ch.cx, py - ch.cy) - ch.rb;
+      if (lb < lb_loc) { lb_loc = lb; c_loc = c; }
+      lbc_loc = dmin(lbc_loc, lb - ch.slack);
+    }
+    Grp<G>::min_dk(lb_loc, c_loc);
+    if constexpr (G >= 2) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<0>(lbc_loc));
+    if constexpr (G >= 4) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<1>(lbc_loc));
+    if constexpr (G >= 8) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<2>(lbc_loc));
+    if constexpr (G >= 16) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<3>(lbc_loc));
+    if constexpr (G >= 32) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<4>(lbc_loc));
+    // exact cull (main points only; cull_thresh = +inf otherwise): every pose of the continuous path keeps
+    // sdf >= lbc_loc > safety_hor (upload_traj), so smoothedL1 is inactive (BEO:316-340, x < 0) whatever
+    // local minimum the reference's search would return: the point contributes exactly zero
+    culled = lbc_loc > cull_thresh;
+    if (culled) { best_d = lbc_loc; best_k = 0; }
+    const int c0 = c_loc;
+    if (!culled) eval_chunk(c0);
+    // 2. every other chunk whose lower bound does not exceed the running minimum
+    int c = culled ? nch : 0;
+    while (c < nch) {
+      const int cc = c + li;
+      bool need = false;
+      if (cc < nch && cc != c0) {
+        const Chunk ch = chunks[cc];
+        const double lb = norm2(px - ch.cx, py - ch.cy) - ch.rb;
+        need = !(lb > best_d);
+      }
+      const unsigned m = Grp<G>::ballot(need);
+      if (m == 0u) { c += G; continue; }
+      const int first = __ffs(m) - 1;
+      eval_chunk(c + first);
+      c = c + first + 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_solve: getSDFofSweptVolume<false,true> (SWM:844-866) without its FD gradient, for the main
 // points of a batch or for the selected GSIP circle samples.
 //  * choiceTInit layer 1 (SWM:549-576, first pass): poses at the scan times do not depend on the
@@ -491,68 +598,15 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       live = (px == px);  // NaN marks an unused slot (whole group)
     }
     if (live) {
-    // ---- choiceTInit layer 1 over the pose table
-    double best_d = 1e9;   // min_dis initial value (SWM:545)
+    // ---- choiceTInit layer 1 over the pose table (or the seed k_round already found for a GSIP sample)
+    double best_d = 1e9;
     int best_k = 0x7fffffff;
     bool culled = false;
-    auto eval_chunk = [&](int c) {
-      double d_loc = 1e300;
-      int k_loc = 0x7fffffff;
-      constexpr int GS = (G < kChunk) ? G : kChunk;
-#pragma unroll
-      for (int m = 0; m < kChunk / GS; ++m) {
-        const int k = c * kChunk + li + GS * m;
-        if (li < kChunk && k < K) {
-          const Pose p = pose[k];
-          const double d = sdf_from_pose<SHAPE>(sp, p, px, py);
-          ++n_scan;
-          if (d < d_loc) { d_loc = d; k_loc = k; }  // k increases with m: earliest kept on ties
-        }
-      }
-      Grp<G>::min_dk(d_loc, k_loc);
-      if (d_loc < best_d || (d_loc == best_d && k_loc < best_k)) { best_d = d_loc; best_k = k_loc; }
-    };
-    if (!prune) {
-      for (int c = 0; c < nch; ++c) eval_chunk(c);
+    if (qs.seed_k) {
+      best_k = qs.seed_k[slot];
+      best_d = qs.seed_d[slot];
     } else {
-      // 1. the chunk with the smallest lower bound gives the first upper bound
-      double lb_loc = 1e300, lbc_loc = 1e300;
-      int c_loc = 0;
-      for (int c = li; c < nch; c += G) {
-        const Chunk ch = chunks[c];
-        const double lb = norm2(px - ch.cx, py - ch.cy) - ch.rb;
-        if (lb < lb_loc) { lb_loc = lb; c_loc = c; }
-        lbc_loc = dmin(lbc_loc, lb - ch.slack);
-      }
-      Grp<G>::min_dk(lb_loc, c_loc);
-      if constexpr (G >= 2) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<0>(lbc_loc));
-      if constexpr (G >= 4) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<1>(lbc_loc));
-      if constexpr (G >= 8) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<2>(lbc_loc));
-      if constexpr (G >= 16) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<3>(lbc_loc));
-      if constexpr (G >= 32) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<4>(lbc_loc));
-      // exact cull (main points only; cull_thresh = +inf otherwise): every pose of the continuous path keeps
-      // sdf >= lbc_loc > safety_hor (upload_traj), so smoothedL1 is inactive (BEO:316-340, x < 0) whatever
-      // local minimum the reference's search would return: the point contributes exactly zero
-      culled = lbc_loc > cull_thresh;
-      if (culled) { best_d = lbc_loc; best_k = 0; }
-      const int c0 = c_loc;
-      if (!culled) eval_chunk(c0);
-      // 2. every other chunk whose lower bound does not exceed the running minimum
-      int c = culled ? nch : 0;
-      while (c < nch) {
-        const int cc = c + li;
-        bool need = false;
-        if (cc < nch && cc != c0) {
-          const Chunk ch = chunks[cc];
-          const double lb = norm2(px - ch.cx, py - ch.cy) - ch.rb;
-          need = !(lb > best_d);
-        }
-        const unsigned m = Grp<G>::ballot(need);
-        if (m == 0u) { c += G; continue; }
-        const int first = __ffs(m) - 1;
-        eval_chunk(c + first);
-        c = c + first + 1;
-      }
+      scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan);
     }
     if (culled) {
       if (li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
@@ -728,6 +782,7 @@ struct GsipState {
   int *solve;       // sample slots to solve in the current iteration (capacity kMaxSlots per point)
   // sample slots [j * stride + batch start + a]
   double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
+  int *sq_k;        // layer-1 seed index of the sample (full-scan mode: sq_ub is then the seed value)
 };
 
 // Per main point after the first solve: exterior -> FD gradient (getGradPrelAtTimeStamp,
@@ -812,7 +867,7 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
 // LP lanes per point (8 or 32): the early rounds have 2 and 6 samples, the later ones 18-21; a
 // point with more samples than lanes is handled in ceil(n / LP) passes.
 constexpr int kRoundBlock = 1024;
-template <int SHAPE, int LP>
+template <int SHAPE, int LP, bool FULL>
 __global__ void __launch_bounds__(kRoundBlock)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
@@ -844,6 +899,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   int *solve = gs.solve + (size_t)start * kMaxSlots;
   const int l = (int)(threadIdx.x & (LP - 1));
   const int hw = (int)(threadIdx.x / LP);
+  unsigned n_scan = 0;   // table evaluations of the cooperative seed scans (FULL)
   const unsigned lt_mask = (1u << l) - 1u;
   auto ballot_g = [&](bool p) -> unsigned {   // bit i <=> lane i of this point's lane group
     const unsigned long long m = __ballot(p);
@@ -939,6 +995,8 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         double theta = theta0;
         for (int q = 0; q < l; ++q) theta += theta_res;
         double ub[NP], umax = -1e300;
+        double sqx_l[NP], sqy_l[NP];
+        int kk[NP];
         bool valid[NP];
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
@@ -946,31 +1004,75 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
           valid[ps] = (theta < theta0 + 2 * kPI) && (j < kMaxSlots);
           n_emit += __popc(ballot_g(valid[ps]));  // theta increases with j: the valid samples are a prefix
           ub[ps] = -1e300;
+          kk[ps] = 0;
+          sqx_l[ps] = 0.0; sqy_l[ps] = 0.0;
           if (valid[ps]) {
             const size_t s = (size_t)j * stride + ia;
             const double qx = cx + 1.0 * r * cos(theta);
             const double qy = cy + 1.0 * r * sin(theta);
-            // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
-            double d2min = 1e300;
-            int c0 = 0;
-            for (int c = 0; c < nch; ++c) {
-              const Chunk ch = chunks[c];
-              const double ex = qx - ch.cx, ey = qy - ch.cy;
-              const double d2 = ex * ex + ey * ey;
-              if (d2 < d2min) { d2min = d2; c0 = c; }
+            sqx_l[ps] = qx; sqy_l[ps] = qy;
+            if constexpr (!FULL) {
+              // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
+              double d2min = 1e300;
+              int c0 = 0;
+              for (int c = 0; c < nch; ++c) {
+                const Chunk ch = chunks[c];
+                const double ex = qx - ch.cx, ey = qy - ch.cy;
+                const double d2 = ex * ex + ey * ey;
+                if (d2 < d2min) { d2min = d2; c0 = c; }
+              }
+              double u = 1e300;
+              const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
+              for (int k = c0 * kChunk; k < k1; ++k) u = dmin(u, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
+              ub[ps] = u;
+              gs.sq_ub[s] = u;
             }
-            double u = 1e300;
-            const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
-            for (int k = c0 * kChunk; k < k1; ++k) u = dmin(u, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
-            ub[ps] = u;
-            gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_ub[s] = u; gs.sq_sdf[s] = kUnsolved;
+            gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_sdf[s] = kUnsolved;
           }
-          umax = fmax(umax, ub[ps]);
           if (ps + 1 < NP) {
 #pragma unroll
             for (int q = 0; q < LP; ++q) theta += theta_res;
           }
         }
+        if constexpr (FULL) {
+          // Tightest bound layer 1 can give: the sample's own seed (the full pruned scan its solve would start
+          // with), found here by 8 cooperating lanes per sample -- LP / 8 samples at a time -- and handed to
+          // k_solve, which then skips its scan.  For shapes / trajectories where the nearest chunk is a poor
+          // guess (sdHorseshoe: 5.3 -> 2 solves per point) this is the difference between solving most samples
+          // and solving the one that matters.
+          constexpr int SG = LP / 8;
+          const int sg = l >> 3;
+          for (int p = 0; p * SG < n_emit; ++p) {
+            const int sidx = p * SG + sg;             // sample this 8-lane sub-group scans in this pass
+            const int slot = sidx / LP;               // uniform over the point's lanes (SG == 1 when NP > 1)
+            double sxs = sqx_l[0], sys = sqy_l[0];
+#pragma unroll
+            for (int ps = 1; ps < NP; ++ps)
+              if (slot == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
+            const double qx = __shfl(sxs, sidx % LP, LP), qy = __shfl(sys, sidx % LP, LP);
+            double bd = -1e300;
+            int bk = 0;
+            if (sidx < n_emit) {
+              bool cu;
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
+            }
+            // hand the result to the lane that owns the sample: sub-group (j % SG) scanned sample j in pass j / SG
+            const double rb = __shfl(bd, (l % SG) * 8, LP);
+            const int rk = __shfl(bk, (l % SG) * 8, LP);
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps)
+              if (valid[ps] && (l + LP * ps) / SG == p) { ub[ps] = rb; kk[ps] = rk; }
+          }
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps)
+            if (valid[ps]) {
+              const size_t s = (size_t)(l + LP * ps) * stride + ia;
+              gs.sq_ub[s] = ub[ps];
+              gs.sq_k[s] = kk[ps];
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) umax = fmax(umax, ub[ps]);
         umax = fmax(umax, Grp<LP>::template xchg<0>(umax));
         umax = fmax(umax, Grp<LP>::template xchg<1>(umax));
         umax = fmax(umax, Grp<LP>::template xchg<2>(umax));
@@ -1017,6 +1119,12 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     }
     if (push_next && l == 0) nxt[s_base[1][hw]] = a;
     __syncthreads();
+  }
+  if constexpr (FULL) {
+    unsigned long long tc = n_scan;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tc += __shfl_xor(tc, m, 64);
+    if ((threadIdx.x & 63) == 0 && tc) { atomicAdd(&ctl->stat_scan, tc); atomicAdd(&ctl->stat_evals, tc); }
   }
 }
 
