@@ -163,3 +163,31 @@ def test_exact_cull_is_invisible(built):
     Tlong = np.asarray(w["T"]) * 8.0                            # 320 s
     ctx.eval_penalty(svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], w["q"], Tlong), Tlong)
     assert ctx.stats()["culled_points"] == 0
+
+
+def test_gsip_bound_modes_are_invisible(built):
+    """The two qualities of GSIP upper bound (nearest-chunk bound vs the sample's own layer-1 scan done by k_round
+    and reused by k_solve) only decide WHICH samples are solved first: per-point results, cost and
+    gradients must be identical, and the full mode must need fewer solves where the cheap bound is poor."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    for cfg, P in (("C2", 40000), ("C3", 60000), ("C4", 40000), ("C5", 20000)):
+        w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
+
+        def run():
+            ctx = _ctx(w)
+            ctx.set_points(w["points"])
+            out = ctx.eval_penalty(w["coeffs"], w["T"])
+            st = ctx.stats()
+            q = ctx.query_points(w["coeffs"], w["T"])
+            return out, st, q
+        (c0, gT0, gC0), st0, q0 = _with_env(dict(SVSDF_UB_FULL=0), run)
+        (c1, gT1, gC1), st1, q1 = _with_env(dict(SVSDF_UB_FULL=1), run)
+        for a, b in zip(q0[:3], q1[:3]):
+            np.testing.assert_array_equal(a, b)          # sdf, t*, gradient direction: bit for bit
+        assert abs(c1 - c0) <= 1e-13 * abs(c0)
+        assert np.abs(gC1 - gC0).max() <= 1e-12 * np.abs(gC0).max()
+        assert np.abs(gT1 - gT0).max() <= 1e-12 * np.abs(gT0).max()
+        assert st1["solves"] <= st0["solves"], (cfg, st0["solves"], st1["solves"])
+        if cfg == "C3":
+            assert st1["solves"] < 0.6 * st0["solves"]
