@@ -109,8 +109,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(4):      # part of the setup: the library settles its launch plan (lane-group widths, GSIP bound
-        step()              # mode) over the first four evaluations after set_points; all give identical results
+    for _ in range(6):      # part of the setup: the library settles its launch plan (lane-group widths, GSIP bound
+        step()              # mode) over the first six evaluations after set_points; all give identical results
     for _ in range(a.warmup):
         step()
     fence()

@@ -69,7 +69,7 @@ struct svsdf_ctx {
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
   bool ub_env = false;         // env SVSDF_UB_FULL=0/1 pins the mode, otherwise run_pipeline picks the faster one
-  int ub_tune = 0;             // 0..3: timing evaluations after a new point set, 4: decided
+  int ub_tune = 0;             // 0..5: timing evaluations after a new point set, 6: decided
   double ub_ms[2] = {0.0, 0.0};
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
@@ -540,19 +540,20 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
 int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   // GSIP upper-bound mode: the cheap bound (8 table poses of the nearest chunk) is enough for some shapes (star:
   // full scans only add 15 %), useless for others (sdHorseshoe: 5.3 -> 2 solves per point, 2x overall).  Both
-  // modes give the same bits, so the choice is made by the clock: after a new point set evaluations 2 and 4 are
-  // timed (1 and 3 warm the adaptive launch plan up in the respective mode), the faster mode is kept.
+  // modes give the same bits, so the choice is made by the clock: after a new point set three evaluations run in
+  // each mode (the first warms the adaptive launch plan up, the better of the other two counts), the faster is kept.
   const int phase = ctx->ub_env ? -1 : ctx->ub_tune;
-  if (phase >= 0 && phase < 4) ctx->ub_full = phase >= 2;
+  if (phase >= 0 && phase < 6) ctx->ub_full = phase >= 3;
   const auto t0 = std::chrono::steady_clock::now();
   int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/true);
   if (rc) return rc;
   rc = finish(ctx, true);
-  if (rc == SVSDF_OK && phase >= 0 && phase < 4) {
+  if (rc == SVSDF_OK && phase >= 0 && phase < 6) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (phase == 1) ctx->ub_ms[0] = ms;
-    if (phase == 3) {
-      ctx->ub_ms[1] = ms;
+    const int m = phase / 3;
+    if (phase % 3 == 1) ctx->ub_ms[m] = ms;                              // the first evaluation in a mode only warms
+    if (phase % 3 == 2) ctx->ub_ms[m] = std::min(ctx->ub_ms[m], ms);     // the launch plan up; best of the next two
+    if (phase == 5) {
       ctx->ub_full = ctx->ub_ms[1] < ctx->ub_ms[0];
       ctx->have_prev_nsolve = ctx->ub_full;   // the launch plan on record is the full-scan one
     }
