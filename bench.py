@@ -3,13 +3,26 @@
 
 One "step" = one call of the inner operator addSaftyPenaOnSweptVolumeParallelTrueSDF (reference
 BEO:774-869) over the whole query-point cloud, points already resident in HBM, through the C ABI
-(include/svsdf_c.h).  Default workload = BASELINE.json configs[1] (C2: star, 16-piece MINCO,
-100k corridor query points per GPU; weak scaling: every rank adds another 100k points).
+(include/svsdf_c.h).
+
+Workloads (svsdf_amd/workload.py, BASELINE.json `configs`):
+  --gpus 1 (default)  C3 = configs[2]: sdHorseshoe, 32-piece MINCO, 1 M corridor query points -- the largest
+                      single-GPU configuration (BASELINE.json quotes its metric on no particular config).
+                      The same line carries, as sub-objects measured in the same run: "north_star" (star,
+                      16 pieces, 1 M points: the workload BASELINE.json's north_star target is quoted on),
+                      "map_distribution" (the headline config on the map-uniform cloud) and the
+                      full-callback time (a14: MINCO forward + penalty + adjoint).
+  --gpus N > 1        C4 = configs[3]: sdHeart, 32 pieces, 4 M points in total, striped over the N GPUs
+                      (strong scaling), one sum of the (19N+1)-double partial per evaluation:
+                        torchrun, one process per GPU  -> RCCL all-reduce (torch.distributed), or
+                        --inprocess, ONE process        -> the C ABI's multi-device context (host combine or
+                                                           in-process RCCL, --combine).
+  --config / --points / --dist override the workload (C1..C5, NS).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 """
 import argparse
 import json
@@ -33,19 +46,28 @@ FLOP_PER_EVAL = 150.0      # nominal FP64 flop per SDF-at-time evaluation (SURVE
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", help="workload config of BASELINE.json (C1..C5)")
-    ap.add_argument("--points", type=int, default=None, help="query points PER GPU (default: the config's)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, help="workload (C1..C5, NS); default C3 at 1 GPU, C4 at N > 1")
+    ap.add_argument("--points", type=int, default=None, help="TOTAL query points (default: the config's)")
     ap.add_argument("--dist", default="corridor", choices=["corridor", "map"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget (rank 0, N=1)")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="one process drives --gpus devices through the C ABI's multi-device context")
+    ap.add_argument("--devices", default=None, help="comma list of HIP ordinals for --inprocess (default 0..N-1; "
+                    "an ordinal may repeat to emulate several stripes on one GPU)")
+    ap.add_argument("--combine", default="auto", choices=["auto", "host", "rccl"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (rank 0, 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the north_star / map_distribution sub-runs")
+    ap.add_argument("--extra-steps", type=int, default=10)
     return ap.parse_args()
 
 
 def cpu_baseline(w, budget_s):
-    """Oracle (CPU port of the reference path, OpenMP schedule(dynamic) over points) timed on the
-    host cores on a bounded prefix sample of the same workload."""
+    """Oracle (CPU restatement of the reference path, OpenMP schedule(dynamic) over points like BEO:785) timed on
+    the host cores on a bounded prefix sample of the same workload: one probe, then 3 timed runs of a sample
+    sized to a third of the budget each; the median is reported and scales linearly in the number of points
+    (independent points, uniformly random order)."""
     from oracle import orc
     cores = os.cpu_count() or 1
     o = orc.Oracle(w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
@@ -53,19 +75,148 @@ def cpu_baseline(w, budget_s):
                    head_state=w["head_state"], tail_state=w["tail_state"])
     o.set_traj(w["coeffs"], w["T"])
     pts = w["points"]
-    probe = min(len(pts), max(256, 8 * cores))
+    probe = min(len(pts), max(512, 16 * cores))
     t0 = time.perf_counter()
     o.penalty(pts[:probe], nthreads=cores)
     tp = time.perf_counter() - t0
-    n = int(min(len(pts), max(probe, probe * budget_s / max(tp, 1e-6))))
-    t0 = time.perf_counter()
-    o.penalty(pts[:n], nthreads=cores)
-    t = time.perf_counter() - t0
+    n = int(min(len(pts), max(probe, probe * (budget_s / 3.0) / max(tp, 1e-6))))
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o.penalty(pts[:n], nthreads=cores)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
     cnt = o.counters()
     return {"value": n / t, "unit": "query-points/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} of {len(pts)} query points of the same workload, oracle/liborc.so "
-                      f"(-O2 -fopenmp, schedule(dynamic)), {t:.2f} s",
+            "sample": f"first {n} of {len(pts)} query points of the same workload (random order, so a prefix is a "
+                      f"uniform subsample; rate scales linearly in points), oracle/liborc.so (-O3 -fopenmp, "
+                      f"schedule(dynamic), {cores} threads), median of 3 runs {sorted(round(x, 3) for x in ts)} s "
+                      f"after 1 probe run",
             "sdf_evals_per_point": cnt["sdf_evals"] / max(n, 1)}
+
+
+class Runner:
+    """One workload resident on this rank's device(s)."""
+
+    def __init__(self, a, name, P_total, dist_name, rank, world, local_rank, tdist, devices):
+        import svsdf_amd
+        from svsdf_amd import workload
+        self.a, self.name, self.tdist, self.world = a, name, tdist, world
+        self.w = w = workload.make(name, P=P_total, dist=dist_name, minco=svsdf_amd.minco_coeffs)
+        self.N = N = len(w["T"])
+        self.P_total = P_total
+        self.opt = opt = svsdf_amd.TrajOptimizer()
+        combine = {"auto": 0, "host": 1, "rccl": 2}[a.combine]
+        opt.setParam(dict(rho=w["rho"], weight_p=w["weight_p"], safety_hor=w["safety_hor"],
+                          inputdata=f"shapes/{w['shape']}.obj", poly_params=w["poly_params"],
+                          polygon=w["polygon"], device=local_rank, devices=devices, combine=combine))
+        opt.setConditions(w["head_state"], w["tail_state"], N)
+        t0 = time.perf_counter()
+        opt.setPoints(w["points"])          # uploaded once; each device keeps its stripe in HBM
+        self.ctx = opt._context()
+        self.set_points_ms = 1e3 * (time.perf_counter() - t0)
+        self.x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+        self.zT, self.zC = np.zeros(N), np.zeros((6 * N, 3))
+
+    def step(self):
+        return self.opt.addSaftyPenaOnSweptVolumeParallelTrueSDF(self.w["T"], self.w["coeffs"], 0.0, self.zT, self.zC)
+
+    def fence(self):
+        import torch
+        if self.tdist is not None:
+            self.tdist.barrier()
+        torch.cuda.synchronize()
+
+    def settle(self):
+        """Setup after set_points, outside every timed region: the first evaluation decides the GSIP bound
+        mode (deterministic rule, svsdf_stats.bound_ratio), the second records the launch plan of that mode."""
+        t0 = time.perf_counter()
+        self.step()
+        first_ms = 1e3 * (time.perf_counter() - t0)
+        self.step()
+        st = self.ctx.stats()
+        return {"set_points_ms": self.set_points_ms, "set_points_library_ms": st["setup_ms"],
+                "first_evaluation_ms": first_ms, "settle_evaluations": 2,
+                "gsip_bound_mode": "full-scan" if st["gsip_bound_mode"] else "cheap-chunk",
+                "bound_ratio": st["bound_ratio"], "rule": "full-scan iff GSIP solves / samples of the first "
+                "evaluation > 0.5 (deterministic; svsdf_stats)"}
+
+    def timed(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        acc = dict(sdf_evals=0, scan_evals=0, solves=0, solve_launches=0, gsip_samples=0)
+        last = None
+        combine_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+            last = self.ctx.stats()
+            for k in acc:
+                acc[k] += last[k]
+            combine_ms += last["combine_ms"]
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        return elapsed, acc, last, combine_ms / steps
+
+    def profiled(self, steps):
+        """Kernel time of the dominant kernel: separate passes with per-launch HIP events on the library's own
+        streams (an event record costs ~6 us per launch, so it stays out of the timed region)."""
+        self.ctx.set_profiling(True)
+        solve_ms = dev_ms = 0.0
+        for _ in range(steps):
+            self.step()
+            st = self.ctx.stats()
+            solve_ms += st["solve_ms"]
+            dev_ms += st["device_ms"]
+        self.ctx.set_profiling(False)
+        return solve_ms / steps, dev_ms / steps
+
+    def full_callback(self, steps, perturb=0.0, seed=7):
+        """a14: costFunctionLmbmParallel (tau -> T, MINCO forward, penalty, adjoint, chain rule).  With
+        perturb > 0 every call sees a slightly different x (relative size `perturb`), like the successive
+        callbacks of an optimisation: the launch plan learned from the previous call no longer matches exactly."""
+        rng = np.random.default_rng(seed)
+        xs = [self.x * (1.0 + perturb * rng.standard_normal(len(self.x))) if perturb else self.x for _ in range(steps)]
+        self.opt.costFunctionLmbmParallel(self.x)
+        self.fence()
+        t0 = time.perf_counter()
+        for x in xs:
+            self.opt.costFunctionLmbmParallel(x)
+        self.fence()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def allreduce_ms(tdist, n, reps=50):
+    """The collective alone: RCCL all-reduce of n doubles (device buffer, in place), HIP-event timed."""
+    import torch
+    t = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(5):
+        tdist.all_reduce(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tdist.all_reduce(t)
+        torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
+def sub_run(a, name, P, dist_name, rank, world, local_rank, tdist, devices, steps):
+    r = Runner(a, name, P, dist_name, rank, world, local_rank, tdist, devices)
+    setup = r.settle()
+    elapsed, acc, last, _ = r.timed(steps, 2)
+    solve_ms, dev_ms = r.profiled(min(steps, 3))
+    out = {"workload": f"{name}: {r.w['shape']}, {r.N} pieces, {P} {dist_name} points", "points_total": P,
+           "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "value": P * steps / elapsed,
+           "unit": "query-points/s", "interior_fraction": last["interior_points"] / max(last["points"], 1),
+           "culled_fraction": last["culled_points"] / max(last["points"], 1),
+           "argmin_solves_per_point": acc["solves"] / steps / max(last["points"], 1),
+           "gsip_bound_mode": setup["gsip_bound_mode"], "k_solve_ms_per_step": solve_ms,
+           "fp64_frac": (acc["sdf_evals"] / steps) * FLOP_PER_EVAL / (solve_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+           "hbm_frac": BYTES_PER_POINT * last["points"] / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "full_callback_ms": r.full_callback(min(steps, 5))}
+    r.opt._ctx.close()
+    return out
 
 
 def main():
@@ -79,119 +230,141 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("SVSDF_BENCH_ONE_GPU"):     # emulation on a 1-GPU box: every rank / stripe on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
+    tdist = None
+    backend = os.environ.get("SVSDF_BENCH_BACKEND", "nccl")   # "gloo": emulation of N ranks on one GPU
     if world > 1 or os.environ.get("SVSDF_BENCH_FORCE_DIST"):   # the latter exercises the RCCL path on 1 GPU
-        import torch.distributed as dist
+        import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            tdist.init_process_group(backend, rank=rank, world_size=world)
+    devices = None
+    n_gpus = world
+    if a.inprocess:
+        if world != 1:
+            raise SystemExit("--inprocess is a single-process mode (do not launch it with torchrun)")
+        devices = [int(v) for v in a.devices.split(",")] if a.devices else list(range(a.gpus))
+        n_gpus = len(devices)
+        if n_gpus < 2:
+            devices = None
+    multi = n_gpus > 1
+    name = a.config or ("C4" if multi else "C3")
+    P_total = a.points or workload.CONFIGS[name]["P"]
 
-    per_gpu = a.points or workload.CONFIGS[a.config]["P"]
-    P_total = per_gpu * world
-    w = workload.make(a.config, P=P_total, dist=a.dist, minco=svsdf_amd.minco_coeffs)
-    N = len(w["T"])
-
-    opt = svsdf_amd.TrajOptimizer()
-    opt.setParam(dict(rho=w["rho"], weight_p=w["weight_p"], safety_hor=w["safety_hor"],
-                      inputdata=f"shapes/{w['shape']}.obj", poly_params=w["poly_params"],
-                      polygon=w["polygon"], device=local_rank))
-    opt.setConditions(w["head_state"], w["tail_state"], N)
-    opt.setPoints(w["points"])          # uploaded once; each rank keeps its stripe in HBM
-    ctx = opt._context()
-
-    def step():
-        return opt.addSaftyPenaOnSweptVolumeParallelTrueSDF(w["T"], w["coeffs"], 0.0, np.zeros(N), np.zeros((6 * N, 3)))
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(6):      # part of the setup: the library settles its launch plan (lane-group widths, GSIP bound
-        step()              # mode) over the first six evaluations after set_points; all give identical results
-    for _ in range(a.warmup):
-        step()
-    fence()
-    evals = scan = solves = launches = interior = samples = culled = 0
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-        st = ctx.stats()
-        evals += st["sdf_evals"]; scan += st["scan_evals"]; solves += st["solves"]
-        launches += st["solve_launches"]; interior = st["interior_points"]; samples += st["gsip_samples"]; culled = st["culled_points"]
-    fence()
-    elapsed = time.perf_counter() - t0
-    # kernel times of the dominant kernel: separate passes with per-launch HIP events on the
-    # library's streams (event records add ~6 us per launch, so they stay out of the timed region)
+    r = Runner(a, name, P_total, a.dist, rank, world, local_rank, tdist, devices)
+    w, N, ctx = r.w, r.N, r.ctx
+    setup = r.settle()
+    elapsed, acc, last, combine_ms = r.timed(a.steps, a.warmup)
     prof_steps = max(1, min(a.steps, 5))
-    ctx.set_profiling(True)
-    solve_ms = dev_ms = 0.0
-    for _ in range(prof_steps):
-        step()
-        st = ctx.stats()
-        solve_ms += st["solve_ms"]; dev_ms += st["device_ms"]
-    ctx.set_profiling(False)
-    fence()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    solve_ms_step, dev_ms_step = r.profiled(prof_steps)
+    r.fence()
+    cb_steps = max(1, min(a.steps, 10))
+    full_cb_ms = r.full_callback(cb_steps)
+    full_cb_pert_ms = r.full_callback(cb_steps, perturb=1e-3)
+    shard_points = last["points"]          # points resident on this process' device(s)
+    evals_rank, interior_rank = acc["sdf_evals"], last["interior_points"]
+    ar_ms = None
+    if tdist is not None:
+        if backend == "nccl":
+            ar_ms = allreduce_ms(tdist, 19 * N + 1)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            agg = torch.tensor([acc["sdf_evals"], acc["solves"], last["interior_points"], acc["scan_evals"],
+                                last["culled_points"]], dtype=torch.float64, device="cuda")
+            tdist.all_reduce(agg, op=tdist.ReduceOp.SUM)
+        else:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            agg = torch.tensor([acc["sdf_evals"], acc["solves"], last["interior_points"], acc["scan_evals"],
+                                last["culled_points"]], dtype=torch.float64)
+            tdist.all_reduce(agg, op=tdist.ReduceOp.SUM)
         elapsed = float(t.item())
-        agg = torch.tensor([evals, solves, interior * a.steps, scan], dtype=torch.float64, device="cuda")
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        evals_all, solves_all, interior_all, scan_all = [float(v) for v in agg.tolist()]
+        evals_all, solves_all, interior_all, scan_all, culled_all = [float(v) for v in agg.tolist()]
     else:
-        evals_all, solves_all, interior_all, scan_all = float(evals), float(solves), float(interior * a.steps), float(scan)
-
+        evals_all, solves_all, interior_all, scan_all, culled_all = (float(acc["sdf_evals"]), float(acc["solves"]),
+                                                                     float(last["interior_points"]), float(acc["scan_evals"]),
+                                                                     float(last["culled_points"]))
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        if tdist is not None:
+            tdist.destroy_process_group()
         return
+
     ms_per_step = 1e3 * elapsed / a.steps
     value = P_total * a.steps / elapsed
-    # dominant kernel = k_solve; rank-0 HIP-event time on the library's own streams
-    solve_ms_step = solve_ms / prof_steps
-    shard = ctx.num_points()
-    ach_gbs = BYTES_PER_POINT * shard / (solve_ms_step * 1e-3) / 1e9
-    ach_tf = (evals / a.steps) * FLOP_PER_EVAL / (solve_ms_step * 1e-3) / 1e12
+    # dominant kernel = k_solve: rank-0 (in-process: slowest device) HIP-event time on the library's own streams
+    pts_dev = shard_points / (n_gpus if a.inprocess and multi else 1)
+    ach_gbs = BYTES_PER_POINT * pts_dev / (solve_ms_step * 1e-3) / 1e9
+    ach_tf = (evals_rank / a.steps / (n_gpus if a.inprocess and multi else 1)) * FLOP_PER_EVAL / (solve_ms_step * 1e-3) / 1e12
     traffic = None
-    try:  # PMC-derived HBM traffic of k_refine per evaluation (collected offline, see profiles/)
+    try:  # PMC-derived HBM traffic of k_solve per evaluation (collected offline, see profiles/)
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic = tr.get(f"{a.config}:{a.dist}:{per_gpu}")
+        traffic = tr.get(f"{name}:{a.dist}:{int(pts_dev)}")
     except Exception:
         pass
+    if multi:
+        how = (f"ONE process, {n_gpus} devices {devices} through the C ABI's multi-device context, "
+               f"{['host', 'host', 'rccl'][last['combine']]} combine of the partials"
+               if a.inprocess else f"{world} processes (torchrun), 1 GPU each, RCCL all-reduce via torch.distributed")
+    else:
+        how = "1 GPU, no collective"
     res = {
         "metric": "SVSDF query-points/sec (cost+grad) per optimizer evaluation",
-        "value": value, "unit": "query-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{a.config}: {w['shape']} shape, {N}-piece MINCO (2.5 s/piece), "
-                               f"{per_gpu} {a.dist} query points per GPU, seed {workload.SEED}",
-                   "points_total": P_total, "pieces": N, "shape": w["shape"], "distribution": a.dist,
-                   "interior_fraction": interior_all / a.steps / P_total,
+        "value": value, "unit": "query-points/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if multi else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{name}: {w['shape']} shape, {N}-piece MINCO (2.5 s/piece), {P_total} {a.dist} "
+                               f"query points in total ({int(pts_dev)} per GPU), seed {workload.SEED}",
+                   "points_total": P_total, "points_per_gpu": int(pts_dev), "pieces": N, "shape": w["shape"],
+                   "distribution": a.dist,
+                   "interior_fraction": interior_all / P_total,
+                   "culled_fraction": culled_all / P_total,
                    "argmin_solves_per_point": solves_all / a.steps / P_total,
-                   "gsip_samples_per_point_rank0": samples / a.steps / max(ctx.num_points(), 1),
-                   "culled_fraction_rank0": culled / max(ctx.num_points(), 1),
-                   "parallelism": f"points striped over {world} GPU(s), 1 all-reduce of {19 * N + 1} f64"},
+                   "gsip_samples_per_point_rank0": acc["gsip_samples"] / a.steps / max(shard_points, 1),
+                   "parallelism": f"points striped over {n_gpus} GPU(s) ({how}); one sum of {19 * N + 1} f64 per evaluation"},
+        "setup": setup,
+        "full_callback_ms": full_cb_ms,
+        "full_callback_perturbed_ms": full_cb_pert_ms,
+        "full_callback_note": "a14 = costFunctionLmbmParallel: tau -> T, host MINCO forward, penalty (this bench's step), "
+                              "MINCO adjoint, chain rule; mean of %d calls.  'perturbed': every call gets x * (1 + 1e-3 * "
+                              "N(0,1)), i.e. the launch plan learned from the previous call is slightly off, as in a "
+                              "real optimisation" % cb_steps,
         "roofline": {"bound": "hbm", "kernel": "k_solve (argmin over t: pruned table scan + scan layers 2-4 + descent; all launches of one evaluation)",
                      "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_unit": "bytes per evaluation (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
-                     "kernel_ms_per_step": solve_ms_step, "launches_per_step": launches / a.steps,
-                     "device_ms_per_step": dev_ms / prof_steps, "profiled_steps": prof_steps,
+                     "kernel_ms_per_step": solve_ms_step, "launches_per_step": acc["solve_launches"] / a.steps,
+                     "device_ms_per_step": dev_ms_step, "profiled_steps": prof_steps,
                      "note": "24 B/point algorithmic; the solve is FP64-VALU bound (SURVEY.md §8d), see fp64",
                      "fp64": {"bound": "fp64_valu", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_tf / FP64_PEAK_TFLOPS,
-                              "sdf_evals_per_step": evals / a.steps, "layer1_evals_per_step": scan / a.steps,
+                              "sdf_evals_per_step": evals_all / a.steps, "layer1_evals_per_step": scan_all / a.steps,
                               "flop_per_eval_nominal": FLOP_PER_EVAL}},
     }
-    if world == 1 and not a.no_cpu_baseline:
+    if multi:
+        res["combine"] = {"ms_allreduce": ar_ms, "ms_combine_inprocess": combine_ms if a.inprocess else None,
+                          "note": "ms_allreduce: RCCL all-reduce of 19N+1 doubles alone (launch + sync, torchrun path); "
+                                  "ms_combine_inprocess: host time from 'all devices done' to 'summed partial on the host'"}
+    # release the headline workload before the sub-runs
+    r.opt._ctx.close()
+    if not multi and not a.no_extras and a.config is None and a.points is None and a.dist == "corridor":
+        res["north_star"] = sub_run(a, "NS", workload.CONFIGS["NS"]["P"], "corridor", rank, world, local_rank, None, None, a.extra_steps)
+        res["map_distribution"] = sub_run(a, name, P_total, "map", rank, world, local_rank, None, None, a.extra_steps)
+    if not multi and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+        if "north_star" in res:
+            wn = workload.make("NS", minco=svsdf_amd.minco_coeffs)
+            cb = cpu_baseline(wn, a.cpu_seconds / 2)
+            res["north_star"]["cpu_baseline"] = cb
+            res["north_star"]["speedup_vs_cpu_baseline"] = res["north_star"]["value"] / cb["value"]
     print(json.dumps(res))
-    if dist is not None:
-        dist.destroy_process_group()
+    if tdist is not None:
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -9,15 +9,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "svsdf_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("svsdf_api.hip", "svsdf_kernels.hpp", "svsdf_shapes.hpp", "svsdf_minco.hpp", "svsdf_points.hpp")] + \
-       [os.path.join(HERE, "..", "include", "svsdf_c.h")]
+import glob
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, "..", "include", "svsdf_c.h")]
 OUT = os.path.join(HERE, "libsvsdf_hip.so")
 
 # -ffp-contract=off: the parity build rounds every operation like the reference's x86-64 build
 # (no FMA contraction); see DESIGN.md "Floating-point policy".
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-result", "-pthread", "-ldl"]
 
 
 def needs_build():

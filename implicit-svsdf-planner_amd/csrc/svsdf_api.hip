@@ -6,16 +6,23 @@
 // per-entry-point citations.  No CPU fallback: without a HIP device every compute entry fails.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/svsdf_c.h"
@@ -31,6 +38,49 @@ namespace {
 thread_local std::string g_last_error;
 }
 
+// One host thread per device of an in-process multi-GPU context.
+struct Worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, done = true, quit = false;
+  int rc = 0;
+  Worker() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        std::function<int()> f = std::move(job);
+        has_job = false;
+        lk.unlock();
+        const int r = f();
+        lk.lock();
+        rc = r;
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void post(std::function<int()> f) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(f);
+    has_job = true;
+    done = false;
+    cv.notify_all();
+  }
+  int wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return done; });
+    return rc;
+  }
+  ~Worker() {
+    { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); }
+    if (th.joinable()) th.join();
+  }
+};
+
 struct svsdf_ctx {
   svsdf_config cfg{};
   int device = 0;
@@ -43,6 +93,7 @@ struct svsdf_ctx {
 
   // points: this rank's shard, Morton-sorted, split into nbatch contiguous batches
   size_t P = 0;
+  bool points_set = false;           // svsdf_set_points was called (P may be 0: an obstacle-free window)
   std::vector<long long> shard_idx;  // original index of shard element j
   double *d_px = nullptr, *d_py = nullptr;
   int nbatch = 1;
@@ -57,7 +108,8 @@ struct svsdf_ctx {
   Pose *d_pose = nullptr;
   Chunk *d_chunks = nullptr;
   size_t pose_cap = 0;
-  double r_bound = 0.0;    // shape bound radius for the layer-1 chunk pruning
+  double r_bound = 0.0;    // shape bound radius for the layer-1 chunk pruning (analytic circumradius + offset)
+  double r_bound_sampled = 0.0;  // max over a polar grid of |q| - sdf(q): self-check, must not exceed r_bound
   double traj_duration = 0.0;
   bool have_duration = false;
   bool host_only = false;  // SVSDF_FLAG_HOST_ONLY: MINCO / callback host logic only, no device
@@ -68,9 +120,10 @@ struct svsdf_ctx {
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
-  bool ub_env = false;         // env SVSDF_UB_FULL=0/1 pins the mode, otherwise run_pipeline picks the faster one
-  int ub_tune = 0;             // 0..5: timing evaluations after a new point set, 6: decided
-  double ub_ms[2] = {0.0, 0.0};
+  bool ub_env = false;         // env SVSDF_UB_FULL=0/1 pins the mode, otherwise run_pipeline decides after one evaluation
+  int ub_tune = 0;             // evaluations since the point set changed that took part in the decision (0 or 1)
+  double ub_ratio = 0.0;       // GSIP solves / GSIP samples of the deciding (cheap-bound) evaluation
+  double ub_threshold = 0.5;   // env SVSDF_UB_RATIO
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
   int G_env = 0, G_late_env = 0;
@@ -106,6 +159,18 @@ struct svsdf_ctx {
   size_t ev_used = 0;
   std::vector<std::pair<size_t, size_t>> refine_events;  // (start, stop) indices into ev_pool
   svsdf_stats stats{};
+
+  // in-process multi-GPU group (svsdf_config::n_devices > 1): this context then owns no device state of its
+  // own, only the host-side callback state below; subs[k] is the single-device context of stripe k
+  std::vector<svsdf_ctx *> subs;
+  std::vector<std::unique_ptr<Worker>> workers;   // one host thread per sub-context
+  int combine = 0;                  // SVSDF_COMBINE_HOST / SVSDF_COMBINE_RCCL (resolved)
+  std::vector<void *> comms;        // ncclComm_t per sub-context (RCCL combine)
+  std::vector<double *> d_red;      // per sub-context all-reduce output (RCCL combine)
+  double *h_red = nullptr;          // pinned: reduced partial read back from subs[0]
+  std::vector<double> comb;         // host-combined [cost | gradC | gradT]
+  const double *h_partial = nullptr;  // where the last evaluation's summed partial lives on the host
+  double combine_ms = 0.0, setup_ms = 0.0;
 
   // full-callback state (TrajOptimizer members BEO:44-60)
   svsdf_host::MincoS3 minco;
@@ -289,6 +354,10 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   double td = 0.0;
   for (int i = 0; i < N; ++i) td += T[i];  // Trajectory::getTotalDuration (TRJ:410-419)
   if (!(td == td) || std::isinf(td)) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite duration");
+  // forwardT (BEO:213-226) only produces positive durations and Trajectory asserts t_max > 0; a non-positive
+  // piece would leave the scan table empty
+  for (int i = 0; i < N; ++i)
+    if (!(T[i] > 0.0)) return fail(ctx, SVSDF_ERR_INVALID, "piece durations must be positive");
   if (td < 3 * 1e2 || !ctx->have_duration) {
     ctx->traj_duration = td;
     ctx->have_duration = true;
@@ -296,7 +365,7 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   const double dur = ctx->traj_duration;
   size_t K = 0;
   for (double t = 0.0; t <= dur; t += 0.15) ++K;
-  if (K > 16000) return fail(ctx, SVSDF_ERR_INVALID, "trajectory duration too long for the scan table");
+  if (K < 1 || K > 16000) return fail(ctx, SVSDF_ERR_INVALID, "trajectory duration out of range for the scan table");
   const size_t need = 19 * (size_t)N + K + (K + kChunk - 1) / kChunk;  // coeffs | T | tk | chunk slack
   if (need > ctx->in_cap) {
     const size_t cap = need + 4096;
@@ -421,7 +490,7 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
 // No host synchronisation: batches run on their own streams, joined back onto ctx->stream.
 int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bool allow_cull) {
   if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
-  if (ctx->P == 0) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
+  if (!ctx->points_set) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->ev_used = 0;
   ctx->refine_events.clear();
@@ -536,31 +605,71 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   return SVSDF_OK;
 }
 
-// Whole device pipeline; leaves [cost, gradC, gradT] (19N+1 doubles) in d_out / h_out.
-int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
-  // GSIP upper-bound mode: the cheap bound (8 table poses of the nearest chunk) is enough for some shapes (star:
-  // full scans only add 15 %), useless for others (sdHorseshoe: 5.3 -> 2 solves per point, 2x overall).  Both
-  // modes give the same bits, so the choice is made by the clock: after a new point set three evaluations run in
-  // each mode (the first warms the adaptive launch plan up, the better of the other two counts), the faster is kept.
-  const int phase = ctx->ub_env ? -1 : ctx->ub_tune;
-  if (phase >= 0 && phase < 6) ctx->ub_full = phase >= 3;
-  const auto t0 = std::chrono::steady_clock::now();
+void fill_mode_stats(svsdf_ctx *ctx) {
+  ctx->stats.gsip_bound_mode = ctx->ub_full ? 1 : 0;
+  ctx->stats.bound_mode_decided = (ctx->ub_env || ctx->ub_tune > 0) ? 1 : 0;
+  ctx->stats.bound_ratio = ctx->ub_ratio;
+  ctx->stats.n_devices = 1;
+  ctx->stats.combine = SVSDF_COMBINE_HOST;
+  ctx->stats.combine_ms = 0.0;
+  ctx->stats.setup_ms = ctx->setup_ms;
+}
+
+// Whole device pipeline of ONE device; leaves [cost, gradC, gradT] (19N+1 doubles) in d_out / h_out.
+int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  if (!ctx->points_set) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
+  if (ctx->P == 0) {
+    // an obstacle-free window (or an empty stripe): the reference's loop over parallel_points_num == 0 adds
+    // nothing (BEO:785) and the callback returns energy + rho * sum(T).  The trajectory is still validated and
+    // traj_duration updated (SWM:376-385); the partial is zero on the host and on the device (collectives).
+    if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 64]");
+    double td = 0.0;
+    for (int i = 0; i < N; ++i) {
+      if (!std::isfinite(T[i])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite duration");
+      if (!(T[i] > 0.0)) return fail(ctx, SVSDF_ERR_INVALID, "piece durations must be positive");
+      td += T[i];
+    }
+    for (size_t i = 0; i < 18 * (size_t)N; ++i)
+      if (!std::isfinite(coeffs[i])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite trajectory input");
+    if (td < 3 * 1e2 || !ctx->have_duration) { ctx->traj_duration = td; ctx->have_duration = true; }
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(ctx->d_out, 0, kOutDoubles * sizeof(double), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::memset(ctx->h_out, 0, kOutDoubles * sizeof(double));
+    ctx->N = N;
+    ctx->stats = svsdf_stats{};
+    fill_mode_stats(ctx);
+    ctx->h_partial = ctx->h_out;
+    return SVSDF_OK;
+  }
+  // GSIP upper-bound mode.  The cheap bound (8 table poses of the nearest chunk) is enough for some shapes (star:
+  // a quarter of the samples get solved, full scans only add work), useless for others (sdHorseshoe: 87 % of the
+  // samples land in the selection band; with the sample's own table scan as the bound 5.3 -> 1.4 solves per
+  // point, 2.4x overall).  Both modes return the same bits, so the choice only costs time.  Rule (deterministic,
+  // one evaluation): the first evaluation after a new point set runs with the cheap bound; if it had to solve
+  // more than half of the GSIP samples it emitted, every later evaluation scans.  (Round 1 timed three
+  // evaluations per mode with the wall clock; the rule reproduces its choices on C1-C5 without the five extra
+  // evaluations and without depending on the box.)
+  const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
+  if (deciding) ctx->ub_full = false;
   int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/true);
   if (rc) return rc;
   rc = finish(ctx, true);
-  if (rc == SVSDF_OK && phase >= 0 && phase < 6) {
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    const int m = phase / 3;
-    if (phase % 3 == 1) ctx->ub_ms[m] = ms;                              // the first evaluation in a mode only warms
-    if (phase % 3 == 2) ctx->ub_ms[m] = std::min(ctx->ub_ms[m], ms);     // the launch plan up; best of the next two
-    if (phase == 5) {
-      ctx->ub_full = ctx->ub_ms[1] < ctx->ub_ms[0];
-      ctx->have_prev_nsolve = ctx->ub_full;   // the launch plan on record is the full-scan one
-    }
-    ctx->ub_tune = phase + 1;
+  if (rc == SVSDF_OK && deciding) {
+    const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
+    const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
+    ctx->ub_ratio = ctx->stats.gsip_samples ? (double)gs / (double)ctx->stats.gsip_samples : 0.0;
+    ctx->ub_full = ctx->ub_ratio > ctx->ub_threshold;
+    if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
+    ctx->ub_tune = 1;
   }
+  fill_mode_stats(ctx);
+  ctx->h_partial = ctx->h_out;
   return rc;
 }
+
+int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T);  // leaf or group (below)
 
 void accumulate(int N, const double *partial, double *cost, double *gradT, double *gradC) {
   *cost += partial[0];
@@ -599,68 +708,80 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   return SVSDF_OK;
 }
 
-// Morton order + striping: which original indices rank `rk` of `ws` owns, in device order.
-// Pure host code (also exported as svsdf_shard_plan).
-void shard_plan(const double *xyz, size_t P, int rk, int ws, int flags, std::vector<long long> &out) {
-  // Morton order so that the 64 lanes of a wave hold spatially adjacent points (similar t*,
-  // similar iteration counts, same interior/exterior class); the sum is order-independent.
-  std::vector<long long> order(P);
+// Morton order of the cloud (pure host): original indices sorted by (Morton code of the quantised xy, input index).
+// The 64 lanes of a wave then hold spatially adjacent points (similar t*, similar iteration counts, same
+// interior/exterior class); the sum is order-independent.
+void morton_order(const double *xyz, size_t P, int flags, std::vector<long long> &order) {
+  order.resize(P);
   std::iota(order.begin(), order.end(), 0ll);
-  if (!(flags & SVSDF_FLAG_KEEP_INPUT_ORDER) && P > 1) {
-    double xmin = std::numeric_limits<double>::infinity(), xmax = -xmin, ymin = xmin, ymax = -xmin;
-    for (size_t i = 0; i < P; ++i) {
-      const double x = xyz[3 * i], y = xyz[3 * i + 1];
-      if (x < xmin) xmin = x;
-      if (x > xmax) xmax = x;
-      if (y < ymin) ymin = y;
-      if (y > ymax) ymax = y;
-    }
-    const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
-    std::vector<uint64_t> key(P);
-    for (size_t i = 0; i < P; ++i) {
-      const double fx = (xyz[3 * i] - xmin) / ext, fy = (xyz[3 * i + 1] - ymin) / ext;
-      const uint32_t qx = (uint32_t)std::min(65535.0, std::max(0.0, fx * 65535.0));
-      const uint32_t qy = (uint32_t)std::min(65535.0, std::max(0.0, fy * 65535.0));
-      key[i] = ((uint64_t)(part1by1(qx) | (part1by1(qy) << 1)) << 32) | (uint64_t)(i & 0xffffffffu);
-    }
-    // order by (morton code, input index): LSD radix sort of the 32 Morton bits, 4 stable 8-bit passes over
-    // keys that start in index order (the low 32 bits carry the index and are never a sort digit)
-    std::vector<uint64_t> tmp(P);
-    for (int pass = 0; pass < 4; ++pass) {
-      const int sh = 32 + 8 * pass;
-      size_t cnt[257] = {0};
-      for (size_t i = 0; i < P; ++i) ++cnt[((key[i] >> sh) & 0xffu) + 1];
-      for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
-      for (size_t i = 0; i < P; ++i) tmp[cnt[(key[i] >> sh) & 0xffu]++] = key[i];
-      key.swap(tmp);
-    }
-    for (size_t i = 0; i < P; ++i) order[i] = (long long)(key[i] & 0xffffffffull);
+  if ((flags & SVSDF_FLAG_KEEP_INPUT_ORDER) || P <= 1) return;
+  double xmin = std::numeric_limits<double>::infinity(), xmax = -xmin, ymin = xmin, ymax = -xmin;
+  for (size_t i = 0; i < P; ++i) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1];
+    if (x < xmin) xmin = x;
+    if (x > xmax) xmax = x;
+    if (y < ymin) ymin = y;
+    if (y > ymax) ymax = y;
   }
-  ws = std::max(1, ws);
-  out.clear();
-  // stripe (not block) so that every rank gets a spatially uniform subsample: interior points
-  // cost up to ~150x an exterior one and cluster in space
-  for (size_t k = (size_t)rk; k < P; k += (size_t)ws) out.push_back(order[k]);
+  const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
+  std::vector<uint64_t> key(P);
+  for (size_t i = 0; i < P; ++i) {
+    const double fx = (xyz[3 * i] - xmin) / ext, fy = (xyz[3 * i + 1] - ymin) / ext;
+    const uint32_t qx = (uint32_t)std::min(65535.0, std::max(0.0, fx * 65535.0));
+    const uint32_t qy = (uint32_t)std::min(65535.0, std::max(0.0, fy * 65535.0));
+    key[i] = ((uint64_t)(part1by1(qx) | (part1by1(qy) << 1)) << 32) | (uint64_t)(i & 0xffffffffu);
+  }
+  // LSD radix sort of the 32 Morton bits, 4 stable 8-bit passes over keys that start in index order (the low 32
+  // bits carry the index and are never a sort digit)
+  std::vector<uint64_t> tmp(P);
+  for (int pass = 0; pass < 4; ++pass) {
+    const int sh = 32 + 8 * pass;
+    size_t cnt[257] = {0};
+    for (size_t i = 0; i < P; ++i) ++cnt[((key[i] >> sh) & 0xffu) + 1];
+    for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+    for (size_t i = 0; i < P; ++i) tmp[cnt[(key[i] >> sh) & 0xffu]++] = key[i];
+    key.swap(tmp);
+  }
+  for (size_t i = 0; i < P; ++i) order[i] = (long long)(key[i] & 0xffffffffull);
 }
 
-int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
-  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+// Stripe `rk` of `ws` of a Morton order: stripes, not blocks, so that every rank gets a spatially uniform
+// subsample (interior points cost up to ~150x an exterior one and cluster in space).
+void stripe_of(const std::vector<long long> &order, int rk, int ws, std::vector<long long> &out) {
+  ws = std::max(1, ws);
+  out.clear();
+  out.reserve(order.size() / (size_t)ws + 1);
+  for (size_t k = (size_t)rk; k < order.size(); k += (size_t)ws) out.push_back(order[k]);
+}
+
+// which original indices rank `rk` of `ws` owns, in device order (also exported as svsdf_shard_plan)
+void shard_plan(const double *xyz, size_t P, int rk, int ws, int flags, std::vector<long long> &out) {
+  if (P > 0xffffffffull) { out.clear(); return; }
+  std::vector<long long> order;
+  morton_order(xyz, P, flags, order);
+  stripe_of(order, rk, ws, out);
+}
+
+// Upload this context's stripe (ctx->shard_idx, already planned) of the host cloud.
+int upload_shard(svsdf_ctx *ctx, const double *xyz) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipDeviceSynchronize());
-  shard_plan(xyz, P, ctx->cfg.rank, ctx->cfg.world_size, ctx->cfg.flags, ctx->shard_idx);
   const size_t Ps = ctx->shard_idx.size();
   if (Ps * kMaxSlots > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard (max ~89M)");
-  ctx->P = Ps;
-  int rc = alloc_point_buffers(ctx, Ps);
-  if (rc) return rc;
   std::vector<double> hx(Ps), hy(Ps);
   for (size_t j = 0; j < Ps; ++j) {
     hx[j] = xyz[3 * ctx->shard_idx[j]];
     hy[j] = xyz[3 * ctx->shard_idx[j] + 1];
     if (!std::isfinite(hx[j]) || !std::isfinite(hy[j])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite query point");
   }
-  HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
+  ctx->P = Ps;
+  ctx->points_set = true;
+  int rc = alloc_point_buffers(ctx, Ps);
+  if (rc) return rc;
+  if (Ps) {
+    HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
+  }
   // batches: contiguous ranges of the sorted shard, pipelined on separate streams
   int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;  // multi-stream batches (SVSDF_BATCHES) measured inconsistent across boxes
   nb = std::max(1, std::min(nb, kMaxBatches));
@@ -671,6 +792,7 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   // fewer lanes.  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
   ctx->have_prev_nsolve = false;
   ctx->ub_tune = 0;
+  ctx->ub_ratio = 0.0;
   if (!ctx->ub_env) ctx->ub_full = false;
   if (!ctx->G_env) {
     ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
@@ -687,6 +809,220 @@ int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   }
   HIPCHK(hipMemcpy(ctx->d_ctl, hc.data(), sizeof(BatchCtl) * kMaxBatches, hipMemcpyHostToDevice));
   return SVSDF_OK;
+}
+
+// ---- in-process multi-GPU group ---------------------------------------------------------------------
+// One host thread per device: kernel launches of the devices are issued concurrently (an evaluation is ~25
+// launches per device) and every thread keeps its device current.
+// run f(k) for every sub-context on its worker thread; first non-zero return code wins
+int group_run(svsdf_ctx *ctx, const std::function<int(int)> &f) {
+  const int G = (int)ctx->subs.size();
+  for (int k = 0; k < G; ++k) ctx->workers[k]->post([&f, k] { return f(k); });
+  int rc = SVSDF_OK;
+  for (int k = 0; k < G; ++k) {
+    const int r = ctx->workers[k]->wait();
+    if (r && !rc) {
+      rc = r;
+      ctx->err = "device " + std::to_string(ctx->subs[k]->device) + " (stripe " + std::to_string(k) + "): " + ctx->subs[k]->err;
+      g_last_error = ctx->err;
+    }
+  }
+  return rc;
+}
+
+// RCCL entry points, resolved lazily (dlopen) so that single-GPU users never load the library
+struct RcclApi {
+  void *h = nullptr;
+  int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (h) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return false;
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    return CommInitAll && CommDestroy && AllReduce;
+  }
+};
+RcclApi g_rccl;
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;   // ncclDataType_t / ncclRedOp_t values of rccl.h (ncclDouble, ncclSum)
+
+void merge_stats(svsdf_ctx *ctx) {
+  svsdf_stats t{};
+  for (svsdf_ctx *s : ctx->subs) {
+    const svsdf_stats &a = s->stats;
+    t.points += a.points; t.interior_points += a.interior_points; t.solves += a.solves;
+    t.gsip_samples += a.gsip_samples; t.sdf_evals += a.sdf_evals; t.scan_evals += a.scan_evals;
+    t.culled_points += a.culled_points;
+    t.device_ms = std::max(t.device_ms, a.device_ms); t.solve_ms = std::max(t.solve_ms, a.solve_ms);
+    t.solve_launches = std::max(t.solve_launches, a.solve_launches);
+    t.gsip_iterations = std::max(t.gsip_iterations, a.gsip_iterations);
+    t.gsip_bound_mode = std::max(t.gsip_bound_mode, a.gsip_bound_mode);
+    t.bound_ratio = std::max(t.bound_ratio, a.bound_ratio);
+  }
+  t.bound_mode_decided = 1;
+  for (svsdf_ctx *s : ctx->subs) t.bound_mode_decided &= s->stats.bound_mode_decided;
+  t.n_devices = (int)ctx->subs.size();
+  t.combine = ctx->combine;
+  t.combine_ms = ctx->combine_ms;
+  t.setup_ms = ctx->setup_ms;
+  ctx->stats = t;
+}
+
+int run_pipeline_group(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  const int G = (int)ctx->subs.size();
+  const size_t plen = 19 * (size_t)N + 1;
+  const bool rccl = ctx->combine == SVSDF_COMBINE_RCCL;
+  int rc = group_run(ctx, [&](int k) -> int {
+    svsdf_ctx *s = ctx->subs[k];
+    int r = run_pipeline_leaf(s, N, coeffs, T);
+    if (r || !rccl) return r;
+    // all-reduce of the (19N+1)-double partial over the in-process communicator, on the device's own stream
+    const int e = g_rccl.AllReduce(s->d_out, ctx->d_red[k], plen, kNcclFloat64, kNcclSum, ctx->comms[k], s->stream);
+    if (e) return fail(s, SVSDF_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
+    if (k == 0 && hipMemcpyAsync(ctx->h_red, ctx->d_red[0], plen * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess)
+      return fail(s, SVSDF_ERR_RCCL, "read-back of the reduced partial failed");
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(s, SVSDF_ERR_RCCL, "stream sync after ncclAllReduce failed");
+    return SVSDF_OK;
+  });
+  if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  ctx->comb.resize(kOutPartial);
+  if (rccl) {
+    std::copy(ctx->h_red, ctx->h_red + plen, ctx->comb.begin());
+  } else {
+    // fixed-order host sum of G pinned partials (G x 5 KB): deterministic, no extra launch or sync
+    for (size_t e = 0; e < plen; ++e) {
+      double a = ctx->subs[0]->h_out[e];
+      for (int k = 1; k < G; ++k) a += ctx->subs[k]->h_out[e];
+      ctx->comb[e] = a;
+    }
+  }
+  ctx->combine_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->N = N;
+  ctx->h_partial = ctx->comb.data();
+  merge_stats(ctx);
+  return SVSDF_OK;
+}
+
+int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+  return ctx->subs.empty() ? run_pipeline_leaf(ctx, N, coeffs, T) : run_pipeline_group(ctx, N, coeffs, T);
+}
+
+int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  if (P > 0xffffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<long long> order;
+  morton_order(xyz, P, ctx->cfg.flags, order);   // once, whatever the number of devices
+  int rc = SVSDF_OK;
+  if (ctx->subs.empty()) {
+    stripe_of(order, ctx->cfg.rank, ctx->cfg.world_size, ctx->shard_idx);
+    rc = upload_shard(ctx, xyz);
+  } else {
+    const int G = (int)ctx->subs.size();
+    rc = group_run(ctx, [&](int k) -> int {
+      svsdf_ctx *s = ctx->subs[k];
+      stripe_of(order, ctx->cfg.rank * G + k, ctx->cfg.world_size * G, s->shard_idx);
+      return upload_shard(s, xyz);
+    });
+    ctx->P = 0;
+    ctx->shard_idx.clear();
+    for (svsdf_ctx *s : ctx->subs) {
+      ctx->P += s->P;
+      ctx->shard_idx.insert(ctx->shard_idx.end(), s->shard_idx.begin(), s->shard_idx.end());
+    }
+    ctx->points_set = rc == SVSDF_OK;
+  }
+  ctx->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (svsdf_ctx *s : ctx->subs) s->setup_ms = ctx->setup_ms;
+  return rc;
+}
+
+// Circumradius about the shape-local origin of each registered shape, from the constants of its SDF
+// (csrc/svsdf_shapes.hpp, i.e. Shape.hpp:531-1476).  All these SDFs are exact distance functions, so
+// sdf(q) >= |q| - R holds for every q with R = this radius (+ the shape offset).
+double shape_circumradius(int shape_id, const double *poly_xy, int nverts) {
+  switch (shape_id) {
+    case SVSDF_SHAPE_sdUnevenCapsule: return 6.0;                              // cap r2 = 1 centred at (0, h = 5)
+    case SVSDF_SHAPE_sdCutDisk: return 5.0;                                    // disk radius r
+    case SVSDF_SHAPE_sdTrapezoid: return std::sqrt(3.0 * 3.0 + 2.0 * 2.0);     // corner (r2, he)
+    case SVSDF_SHAPE_sdRhombus: return 4.5;                                    // vertex (0, b.y)
+    case SVSDF_SHAPE_star: return 2.8;                                         // outer tips at r
+    case SVSDF_SHAPE_sdTunnel: return std::sqrt(2.5 * 2.5 + 1.5 * 1.5);        // box corner (wh.x, wh.y) vs arch radius wh.x
+    case SVSDF_SHAPE_sdHorseshoe: return std::hypot(1.5 + 0.20, 1.55);         // far corner of a leg: (r + w.y, w.x)
+    case SVSDF_SHAPE_sdHeart: return 4.0 * (std::sqrt(0.25 * 0.25 + 0.75 * 0.75) + std::sqrt(2.0) / 4.0);  // lobe circle
+    case SVSDF_SHAPE_sdOrientedVesica: return std::sqrt(2.0 * 2.0 + 4.0 * 4.0);  // tips a, b
+    case SVSDF_SHAPE_sdRoundedCross: return 2.0;                               // tips (1, 0), (0, h) scaled by 2
+    case SVSDF_SHAPE_sdRoundedX: return 3.0 / std::sqrt(2.0) + 0.25;           // arm end (w/2, w/2) + r
+    case SVSDF_SHAPE_bigX: return 5.0 / std::sqrt(2.0) + 0.25;
+    case SVSDF_SHAPE_sdMoon: return 3.0;                                       // outer disk ra
+    case SVSDF_SHAPE_sdPie: return 3.0;
+    case SVSDF_SHAPE_sdPie2: return 3.0;
+    case SVSDF_SHAPE_sdArc: return 2.3333 + 0.5;                               // ra + rb
+    default: {
+      double r = 0.0;
+      for (int i = 0; i < nverts; ++i) r = std::max(r, std::hypot(poly_xy[2 * i], poly_xy[2 * i + 1]));
+      return r;
+    }
+  }
+}
+
+// In-process multi-GPU context: one single-device sub-context (and one host thread) per entry of cfg->devices.
+svsdf_ctx *create_group(const svsdf_config *cfg, int ndev) {
+  const int G = cfg->n_devices;
+  bool distinct = true;
+  for (int k = 0; k < G; ++k) {
+    if (cfg->devices[k] < 0 || cfg->devices[k] >= ndev) {
+      g_last_error = "svsdf_create: devices[" + std::to_string(k) + "] is not a visible HIP device";
+      return nullptr;
+    }
+    for (int j = 0; j < k; ++j) distinct = distinct && cfg->devices[j] != cfg->devices[k];
+  }
+  svsdf_ctx *g = new svsdf_ctx();
+  g->cfg = *cfg;
+  g->cfg.polygon_xy = nullptr;
+  g->device = cfg->devices[0];
+  g->combine = cfg->combine == SVSDF_COMBINE_RCCL ? SVSDF_COMBINE_RCCL : SVSDF_COMBINE_HOST;
+  if (const char *e = std::getenv("SVSDF_COMBINE")) g->combine = (std::string(e) == "rccl") ? SVSDF_COMBINE_RCCL : SVSDF_COMBINE_HOST;
+  auto bail = [&](const std::string &m) -> svsdf_ctx * {
+    g_last_error = m;
+    svsdf_destroy(g);
+    return nullptr;
+  };
+  for (int k = 0; k < G; ++k) {
+    svsdf_config c = *cfg;
+    c.n_devices = 0;
+    c.device = cfg->devices[k];
+    c.rank = cfg->rank * G + k;
+    c.world_size = cfg->world_size * G;
+    svsdf_ctx *s = svsdf_create(&c);
+    if (!s) return bail("svsdf_create: device " + std::to_string(c.device) + ": " + g_last_error);
+    g->subs.push_back(s);
+    g->workers.emplace_back(new Worker());
+  }
+  g->r_bound = g->subs[0]->r_bound;
+  if (g->combine == SVSDF_COMBINE_RCCL) {
+    if (!distinct) return bail("svsdf_create: SVSDF_COMBINE_RCCL needs distinct devices (one communicator rank per GPU)");
+    if (!g_rccl.load()) return bail("svsdf_create: librccl.so could not be loaded (SVSDF_COMBINE_RCCL)");
+    g->comms.assign(G, nullptr);
+    const int e = g_rccl.CommInitAll(g->comms.data(), G, cfg->devices);
+    if (e) { g->comms.clear(); return bail(std::string("svsdf_create: ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error")); }
+    g->d_red.assign(G, nullptr);
+    for (int k = 0; k < G; ++k)
+      if (hipSetDevice(cfg->devices[k]) != hipSuccess || hipMalloc((void **)&g->d_red[k], kOutPartial * sizeof(double)) != hipSuccess)
+        return bail("svsdf_create: allocation of the all-reduce buffer failed");
+    if (hipHostMalloc((void **)&g->h_red, kOutPartial * sizeof(double), hipHostMallocDefault) != hipSuccess)
+      return bail("svsdf_create: pinned allocation failed");
+  }
+  return g;
 }
 
 }  // namespace
@@ -728,6 +1064,10 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     g_last_error = "svsdf_create: invalid config";
     return nullptr;
   }
+  if (cfg->n_devices < 0 || cfg->n_devices > SVSDF_MAX_DEVICES || cfg->combine < 0 || cfg->combine > SVSDF_COMBINE_RCCL) {
+    g_last_error = "svsdf_create: n_devices out of range [0, 8] or unknown combine mode";
+    return nullptr;
+  }
   if (cfg->flags & SVSDF_FLAG_HOST_ONLY) {
     svsdf_ctx *h = new svsdf_ctx();
     h->cfg = *cfg;
@@ -740,6 +1080,8 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     g_last_error = "svsdf_create: no HIP device (this library has no CPU fallback)";
     return nullptr;
   }
+  // (one device + RCCL combine is accepted too: a 1-rank communicator, for measuring the collective's fixed cost)
+  if (cfg->n_devices >= 2 || (cfg->n_devices == 1 && cfg->combine == SVSDF_COMBINE_RCCL)) return create_group(cfg, ndev);
   svsdf_ctx *ctx = new svsdf_ctx();
   ctx->cfg = *cfg;
   ctx->cfg.polygon_xy = nullptr;
@@ -818,7 +1160,16 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
       hipHostMalloc((void **)&ctx->h_out, kOutDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
     return bail("device allocation failed");
   if (hipMemset(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl) + 8 * 8 * (kMaxIter + 4)) != hipSuccess) return bail("hipMemset failed");
-  {  // shape bound radius R: sdf_shape(q) >= |q| - R, sampled on a polar grid + safety margin
+  {  // shape bound radius R with sdf_shape(q) >= |q| - R for every q: the shape's circumradius about the body origin
+     // (analytic, per shape; shape_circumradius above) plus the length of its offset (Shape.hpp:281-294).  The polar
+     // sample of |q| - sdf(q) (k_rbound, out to 60 m) is kept as a self-check of that bound, not as its source.
+    std::vector<double> pv;
+    if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
+      pv.resize(2 * (size_t)sp.nverts);
+      if (hipMemcpy(pv.data(), ctx->d_poly, pv.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return bail("hipMemcpy polygon failed");
+    }
+    const double r0 = shape_circumradius(cfg->shape_id, pv.data(), sp.nverts);
+    const double analytic = (r0 + std::hypot(sp.tx, sp.ty)) * (1.0 + 1e-12) + 1e-6;
     if (hipMemset(ctx->d_out, 0, sizeof(double)) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;
     const unsigned grid = (unsigned)((nrad * nang + kBlock - 1) / kBlock);
@@ -829,7 +1180,11 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     if (hipMemcpyAsync(&rb, ctx->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
       return bail("shape bound kernel failed");
-    ctx->r_bound = rb + 0.05;
+    ctx->r_bound_sampled = rb;
+    if (rb > analytic)
+      return bail("svsdf_create: sampled shape bound " + std::to_string(rb) + " exceeds the analytic circumradius " +
+                  std::to_string(analytic) + " (internal error: the pruning bound would be unsafe)");
+    ctx->r_bound = analytic;
     ctx->sp.r_bound = ctx->r_bound;
   }
   return ctx;
@@ -838,6 +1193,17 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
 void svsdf_destroy(svsdf_ctx *ctx) {
   if (!ctx) return;
   if (ctx->host_only) { delete ctx; return; }
+  if (!ctx->subs.empty() || !ctx->workers.empty()) {
+    ctx->workers.clear();   // joins the threads
+    for (size_t k = 0; k < ctx->comms.size(); ++k)
+      if (ctx->comms[k] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comms[k]);
+    for (size_t k = 0; k < ctx->d_red.size(); ++k)
+      if (ctx->d_red[k]) { (void)hipSetDevice(ctx->subs[k]->device); (void)hipFree(ctx->d_red[k]); }
+    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    for (svsdf_ctx *s : ctx->subs) svsdf_destroy(s);
+    delete ctx;
+    return;
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {ctx->d_poly, ctx->d_px, ctx->d_py, ctx->d_traj, ctx->d_in, ctx->d_pose, ctx->d_chunks,
@@ -869,9 +1235,11 @@ int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P) {
 int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P) {
   if (!ctx || (!d_xyz_aos && P)) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_points_device: null argument");
   if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  // The Morton order and the stripes are planned on the host (the plan is shared by every device and rank):
+  // one D2H of the cloud, then the normal upload.  One-time setup per optimisation, never in the timed region.
   HIPCHK(hipSetDevice(ctx->device));
   std::vector<double> h(3 * P);
-  HIPCHK(hipMemcpy(h.data(), d_xyz_aos, 3 * P * sizeof(double), hipMemcpyDeviceToHost));
+  if (P) HIPCHK(hipMemcpy(h.data(), d_xyz_aos, 3 * P * sizeof(double), hipMemcpyDeviceToHost));
   return set_points_host(ctx, h.data(), P);
 }
 
@@ -888,7 +1256,17 @@ int svsdf_eval_penalty_partial(svsdf_ctx *ctx, int N, const double *coeffs, cons
   if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_eval_penalty_partial: null argument");
   int rc = run_pipeline(ctx, N, coeffs, T);
   if (rc) return rc;
-  if (d_partial) *d_partial = ctx->d_out;
+  double *dp = ctx->d_out;
+  if (!ctx->subs.empty()) {
+    // multi-process x multi-device: the node-local sum goes back to device 0 for the caller's collective
+    svsdf_ctx *s0 = ctx->subs[0];
+    dp = (ctx->combine == SVSDF_COMBINE_RCCL) ? ctx->d_red[0] : s0->d_out;
+    if (ctx->combine != SVSDF_COMBINE_RCCL) {
+      HIPCHK(hipSetDevice(s0->device));
+      HIPCHK(hipMemcpy(dp, ctx->comb.data(), (19 * (size_t)N + 1) * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  if (d_partial) *d_partial = dp;
   if (partial_len) *partial_len = 19 * (size_t)N + 1;
   return SVSDF_OK;
 }
@@ -903,22 +1281,56 @@ int svsdf_accumulate_partial(svsdf_ctx *ctx, int N, const double *partial_host, 
   return SVSDF_OK;
 }
 
+int svsdf_sum_partials(const double *partials, int G, size_t len, double *out) {
+  if (!partials || !out || G < 1) return SVSDF_ERR_INVALID;
+  for (size_t e = 0; e < len; ++e) {
+    double a = partials[e];
+    for (int k = 1; k < G; ++k) a += partials[(size_t)k * len + e];
+    out[e] = a;
+  }
+  return SVSDF_OK;
+}
+
+int svsdf_set_conditions(svsdf_ctx *ctx, const double head_state[9], const double tail_state[9]) {
+  if (!ctx || !head_state || !tail_state) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_conditions: null argument");
+  for (int i = 0; i < 9; ++i)
+    if (!std::isfinite(head_state[i]) || !std::isfinite(tail_state[i]))
+      return fail(ctx, SVSDF_ERR_NONFINITE, "svsdf_set_conditions: non-finite boundary state");
+  std::copy(head_state, head_state + 9, ctx->cfg.head_state);
+  std::copy(tail_state, tail_state + 9, ctx->cfg.tail_state);
+  return SVSDF_OK;
+}
+
 int svsdf_eval_penalty(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *cost,
                        double *gradT, double *gradC) {
   if (!ctx || !coeffs || !T || !cost || !gradT || !gradC)
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_eval_penalty: null argument");
   int rc = run_pipeline(ctx, N, coeffs, T);
   if (rc) return rc;
-  return svsdf_accumulate_partial(ctx, N, ctx->h_out, cost, gradT, gradC);
+  return svsdf_accumulate_partial(ctx, N, ctx->h_partial, cost, gradT, gradC);
 }
 
 int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *sdf,
                        double *tstar, double *grad_xy) {
   if (!ctx || !coeffs || !T) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_query_points: null argument");
+  if (!ctx->subs.empty()) {   // per device, concatenated in svsdf_shard_indices order
+    std::vector<size_t> off(ctx->subs.size() + 1, 0);
+    for (size_t k = 0; k < ctx->subs.size(); ++k) off[k + 1] = off[k] + ctx->subs[k]->P;
+    const int rcg = group_run(ctx, [&](int k) -> int {
+      return svsdf_query_points(ctx->subs[k], N, coeffs, T, sdf ? sdf + off[k] : nullptr, tstar ? tstar + off[k] : nullptr,
+                                grad_xy ? grad_xy + 2 * off[k] : nullptr);
+    });
+    if (!rcg) merge_stats(ctx);
+    return rcg;
+  }
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  if (!ctx->points_set) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
+  if (ctx->P == 0) return SVSDF_OK;
   int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/false);  // per-point outputs need every solve
   if (rc) return rc;
   rc = finish(ctx, false);
   if (rc) return rc;
+  fill_mode_stats(ctx);
   const size_t P = ctx->P;
   if (sdf) HIPCHK(hipMemcpy(sdf, ctx->d_res_sdf, P * sizeof(double), hipMemcpyDeviceToHost));
   if (tstar) HIPCHK(hipMemcpy(tstar, ctx->d_res_t, P * sizeof(double), hipMemcpyDeviceToHost));
@@ -933,6 +1345,7 @@ int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double
 
 long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, int n) {
   if (!ctx || ctx->host_only || n < 2) return -1;
+  if (!ctx->subs.empty()) return svsdf_debug_sincos_mismatches(ctx->subs[0], lo, hi, n);
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
   unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_out);
   if (hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1;
@@ -947,6 +1360,15 @@ long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, in
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
   if (!ctx) return SVSDF_ERR_INVALID;
   ctx->profile = enable != 0;
+  for (svsdf_ctx *s : ctx->subs) s->profile = enable != 0;
+  return SVSDF_OK;
+}
+
+int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]) {
+  if (!ctx || !out2) return SVSDF_ERR_INVALID;
+  const svsdf_ctx *c = ctx->subs.empty() ? ctx : ctx->subs[0];
+  out2[0] = c->r_bound;
+  out2[1] = c->r_bound_sampled;
   return SVSDF_OK;
 }
 
@@ -961,6 +1383,11 @@ int svsdf_check_sub_sw_collision(svsdf_ctx *ctx, size_t n_edges, const double *f
                                  const double *child_states, const size_t *pts_offset, const double *pts_xy,
                                  unsigned char *free_out) {
   if (!ctx || ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "svsdf_check_sub_sw_collision: no device context");
+  if (!ctx->subs.empty()) {
+    const int r = svsdf_check_sub_sw_collision(ctx->subs[0], n_edges, father_states, child_states, pts_offset, pts_xy, free_out);
+    if (r) ctx->err = ctx->subs[0]->err;
+    return r;
+  }
   if (n_edges == 0) return SVSDF_OK;
   if (!father_states || !child_states || !pts_offset || !free_out)
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_check_sub_sw_collision: null argument");
@@ -1026,6 +1453,12 @@ int svsdf_shape_kernels(svsdf_ctx *ctx, int kernel_size, int kernel_count, doubl
                         double safemargin, unsigned char *map_out, unsigned char *bytes_out, double *yaw_out,
                         int *loop_count) {
   if (!ctx || ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "svsdf_shape_kernels: no device context");
+  if (!ctx->subs.empty()) {
+    const int r = svsdf_shape_kernels(ctx->subs[0], kernel_size, kernel_count, kernel_resolution, safemargin, map_out,
+                                      bytes_out, yaw_out, loop_count);
+    if (r) ctx->err = ctx->subs[0]->err;
+    return r;
+  }
   if (kernel_size <= 0 || kernel_count <= 0 || kernel_size > 4096 || kernel_count > 65536 || !map_out)
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_shape_kernels: bad argument");
   if (ctx->cfg.shape_id == SVSDF_SHAPE_Polygon)
@@ -1237,8 +1670,8 @@ double svsdf_lmbm_evaluate(void *vctx, const double *x, double *g, const int n) 
   if (run_pipeline(ctx, N, ctx->cm.data(), ctx->T.data())) return inf;
   const size_t plen = 19 * (size_t)N + 1;
   for (size_t e = 0; e < plen; ++e)
-    if (!std::isfinite(ctx->h_out[e])) return inf;
-  return lmbm_complete(ctx, ctx->h_out, x, g, n);
+    if (!std::isfinite(ctx->h_partial[e])) return inf;
+  return lmbm_complete(ctx, ctx->h_partial, x, g, n);
 }
 
 int svsdf_last_costs(const svsdf_ctx *ctx, double costs3[3]) {

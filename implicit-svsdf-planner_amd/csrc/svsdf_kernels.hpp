@@ -1153,69 +1153,103 @@ k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ res_t, const double *__restrict__ res_gx,
            const double *__restrict__ res_gy, double safety_hor, double weight_p,
            double *__restrict__ block_partials, int *__restrict__ nonfinite) {
+  // Deterministic (bit-reproducible run to run): no floating-point atomics.  Every wave owns a private
+  // accumulator row in LDS; per grid-stride step the wave walks the distinct piece ids among its active lanes
+  // (lowest lane first), sums each of the 20 per-point terms of that piece with a fixed xor butterfly (every
+  // lane ends with the same bits) and lane 0 adds the totals to the wave's row.  The point -> (block, wave, lane,
+  // step) assignment depends on P and the grid only; rows are then summed in wave order, block partials in block
+  // order (k_final).  Morton-sorted neighbours share their piece, so a wave sees 1-3 distinct ids per step.
   extern __shared__ double asm_lds[];
   const TrajL tr = stage_traj(trg, asm_lds);
   const int N = tr.N;
   const int plen = 19 * N + 1;
-  double *acc = asm_lds + traj_lds_doubles(N);
-  for (int e = threadIdx.x; e < plen; e += blockDim.x) acc[e] = 0.0;
+  constexpr int kWaves = kBlock / 64;
+  double *acc_all = asm_lds + traj_lds_doubles(N);
+  for (int e = threadIdx.x; e < kWaves * plen; e += blockDim.x) acc_all[e] = 0.0;
   __syncthreads();
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
-    const double px = px_[idx], py = py_[idx];
-    const double sdf_value = res_sdf[idx];
-    const double time_star = res_t[idx];
-    double gr0 = res_gx[idx], gr1 = res_gy[idx];
-    if (!(sdf_value == sdf_value) || !(time_star == time_star) || !(gr0 == gr0) || !(gr1 == gr1))
-      atomicAdd(nonfinite, 1);
-    double sdf_cost = -1.0, sdf_out_grad = 0.0;
-    smoothed_l1(safety_hor - sdf_value, 0.01, sdf_cost, sdf_out_grad);
-    if (sdf_cost > 0) {
-      const int i = locate_piece(tr, time_star, 0);
-      const double *c = tr.c + i * 18;
-      const double s1 = time_star - tr.S[i];
-      const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-      const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
-      const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
-      double pos[3], vel[3];
+  const int lane = (int)(threadIdx.x & 63);
+  double *acc = acc_all + (size_t)(threadIdx.x >> 6) * plen;
+  int bad = 0;
+  for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {
+    const int idx = base + (int)threadIdx.x;
+    bool act = false;
+    int i = -1;
+    double v[20];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        double p = 0.0, v = 0.0;
+    for (int q = 0; q < 20; ++q) v[q] = 0.0;
+    if (idx < P) {
+      const double px = px_[idx], py = py_[idx];
+      const double sdf_value = res_sdf[idx];
+      const double time_star = res_t[idx];
+      double gr0 = res_gx[idx], gr1 = res_gy[idx];
+      if (!(sdf_value == sdf_value) || !(time_star == time_star) || !(gr0 == gr0) || !(gr1 == gr1)) ++bad;
+      double sdf_cost = -1.0, sdf_out_grad = 0.0;
+      smoothed_l1(safety_hor - sdf_value, 0.01, sdf_cost, sdf_out_grad);
+      if (sdf_cost > 0) {
+        i = locate_piece(tr, time_star, 0);
+        const double *c = tr.c + i * 18;
+        const double s1 = time_star - tr.S[i];
+        const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+        const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+        const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+        double pos[3], vel[3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { p += c[k * 3 + d] * beta0[k]; v += c[k * 3 + d] * beta1[k]; }
-        pos[d] = p; vel[d] = v;
-      }
-      const double yaw = pos[2];
-      double sy, cy;
-      sincos(yaw, &sy, &cy);
-      if (sdf_value < 0) {  // BEO:832
-        const double gx = cy * gr0 + sy * gr1;
-        const double gy = (-sy) * gr0 + cy * gr1;
-        gr0 = gx; gr1 = gy;
-      }
-      // grad_cost_p_sw (BEO:1031-1066) with St = I
-      const double mrx = (-cy) * gr0 + (sy) * gr1;
-      const double mry = (-sy) * gr0 + (-cy) * gr1;
-      const double sgx = -sdf_out_grad * mrx, sgy = -sdf_out_grad * mry;
-      const double dx = px - pos[0], dy = py - pos[1];
-      const double v0 = (-sy) * dx + (cy) * dy;
-      const double v1 = (-cy) * dx + (-sy) * dy;
-      const double grad_yaw = (-sdf_out_grad * gr0) * v0 + (-sdf_out_grad * gr1) * v1;
-      const double gPx = weight_p * sgx, gPy = weight_p * sgy, gYaw = weight_p * grad_yaw;
-      const double pena = weight_p * sdf_cost;
-      const double gdT = -((gPx * vel[0] + gPy * vel[1]) + gYaw * vel[2]);
-      atomicAdd(&acc[0], pena);
+        for (int d = 0; d < 3; ++d) {
+          double p = 0.0, vv = 0.0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        atomicAdd(&acc[1 + 0 * 6 * N + 6 * i + k], beta0[k] * gPx);
-        atomicAdd(&acc[1 + 1 * 6 * N + 6 * i + k], beta0[k] * gPy);
-        atomicAdd(&acc[1 + 2 * 6 * N + 6 * i + k], beta0[k] * gYaw);
+          for (int k = 0; k < 6; ++k) { p += c[k * 3 + d] * beta0[k]; vv += c[k * 3 + d] * beta1[k]; }
+          pos[d] = p; vel[d] = vv;
+        }
+        const double yaw = pos[2];
+        double sy, cy;
+        sincos(yaw, &sy, &cy);
+        if (sdf_value < 0) {  // BEO:832
+          const double gx = cy * gr0 + sy * gr1;
+          const double gy = (-sy) * gr0 + cy * gr1;
+          gr0 = gx; gr1 = gy;
+        }
+        // grad_cost_p_sw (BEO:1031-1066) with St = I
+        const double mrx = (-cy) * gr0 + (sy) * gr1;
+        const double mry = (-sy) * gr0 + (-cy) * gr1;
+        const double sgx = -sdf_out_grad * mrx, sgy = -sdf_out_grad * mry;
+        const double dx = px - pos[0], dy = py - pos[1];
+        const double v0 = (-sy) * dx + (cy) * dy;
+        const double v1 = (-cy) * dx + (-sy) * dy;
+        const double grad_yaw = (-sdf_out_grad * gr0) * v0 + (-sdf_out_grad * gr1) * v1;
+        const double gPx = weight_p * sgx, gPy = weight_p * sgy, gYaw = weight_p * grad_yaw;
+        v[0] = weight_p * sdf_cost;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[1 + k] = beta0[k] * gPx; v[7 + k] = beta0[k] * gPy; v[13 + k] = beta0[k] * gYaw; }
+        v[19] = -((gPx * vel[0] + gPy * vel[1]) + gYaw * vel[2]);
+        act = true;
       }
-      atomicAdd(&acc[1 + 18 * N + i], gdT);
+    }
+    unsigned long long m = __ballot(act);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      const int i0 = __shfl(i, src, 64);
+      const bool sel = act && (i == i0);
+#pragma unroll
+      for (int q = 0; q < 20; ++q) {
+        double s = sel ? v[q] : 0.0;
+#pragma unroll
+        for (int x = 1; x <= 32; x <<= 1) s += __shfl_xor(s, x, 64);
+        if (lane == 0) {
+          const int e = (q == 0) ? 0 : (q == 19) ? (1 + 18 * N + i0) : (1 + ((q - 1) / 6) * 6 * N + 6 * i0 + (q - 1) % 6);
+          acc[e] += s;
+        }
+      }
+      m &= ~__ballot(sel);
     }
   }
+  if (bad) atomicAdd(nonfinite, bad);
   __syncthreads();
-  for (int e = threadIdx.x; e < plen; e += blockDim.x)
-    block_partials[(size_t)e * gridDim.x + blockIdx.x] = acc[e];
+  for (int e = threadIdx.x; e < plen; e += blockDim.x) {
+    double s = acc_all[e];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += acc_all[(size_t)w * plen + e];
+    block_partials[(size_t)e * gridDim.x + blockIdx.x] = s;
+  }
 }
 
 // One wave per entry: fixed-order sum over the block partials.

@@ -26,6 +26,7 @@ EXPORTS = [
     "svsdf_map_create", "svsdf_map_destroy", "svsdf_map_info", "svsdf_map_gather", "svsdf_pcd_read_ascii",
     "svsdf_check_sub_sw_collision", "svsdf_shape_kernels",
     "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
+    "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
 ]
 
 
@@ -49,14 +50,17 @@ class Config(C.Structure):
     _fields_ = [("shape_id", C.c_int), ("poly_params", C.c_double * 3), ("safety_hor", C.c_double),
                 ("weight_p", C.c_double), ("rho", C.c_double), ("head_state", C.c_double * 9),
                 ("tail_state", C.c_double * 9), ("device", C.c_int), ("polygon_nverts", C.c_int),
-                ("polygon_xy", _dp), ("rank", C.c_int), ("world_size", C.c_int), ("flags", C.c_int)]
+                ("polygon_xy", _dp), ("rank", C.c_int), ("world_size", C.c_int), ("flags", C.c_int),
+                ("n_devices", C.c_int), ("devices", C.c_int * 8), ("combine", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("points", C.c_ulonglong), ("interior_points", C.c_ulonglong),
                 ("solves", C.c_ulonglong), ("gsip_samples", C.c_ulonglong), ("sdf_evals", C.c_ulonglong),
                 ("scan_evals", C.c_ulonglong), ("device_ms", C.c_double), ("solve_ms", C.c_double),
-                ("solve_launches", C.c_uint), ("gsip_iterations", C.c_uint), ("culled_points", C.c_ulonglong)]
+                ("solve_launches", C.c_uint), ("gsip_iterations", C.c_uint), ("culled_points", C.c_ulonglong),
+                ("gsip_bound_mode", C.c_int), ("bound_mode_decided", C.c_int), ("bound_ratio", C.c_double),
+                ("n_devices", C.c_int), ("combine", C.c_int), ("combine_ms", C.c_double), ("setup_ms", C.c_double)]
 
 
 class SvsdfError(RuntimeError):
@@ -64,8 +68,8 @@ class SvsdfError(RuntimeError):
 
 
 def lib_path():
-    """In-tree HIP library.  SVSDF_LIB_VARIANT=strict selects the bit-reproducible parity build
-    (libsvsdf_hip_strict.so: no FMA contraction, reference operation order)."""
+    """In-tree HIP library.  SVSDF_LIB_VARIANT=<v> loads libsvsdf_hip_<v>.so instead (experimental builds
+    made by tools/ scripts for A/B measurements; nothing in tests/ or bench.py sets it)."""
     v = os.environ.get("SVSDF_LIB_VARIANT", "")
     return os.path.join(_PKG, "libsvsdf_hip_%s.so" % v if v else "libsvsdf_hip.so")
 
@@ -98,6 +102,9 @@ def lib():
     L.svsdf_eval_penalty_partial.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_size_t)]
     L.svsdf_accumulate_partial.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
+    L.svsdf_sum_partials.argtypes = [_dp, C.c_int, C.c_size_t, _dp]
+    L.svsdf_set_conditions.argtypes = [C.c_void_p, _dp, _dp]
+    L.svsdf_shape_bound.argtypes = [C.c_void_p, _dp]
     L.svsdf_lmbm_evaluate.restype = C.c_double
     L.svsdf_lmbm_evaluate.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
     L.svsdf_last_costs.argtypes = [C.c_void_p, _dp]
@@ -233,6 +240,17 @@ class OccupancyMap:
 
 FLAG_KEEP_INPUT_ORDER = 1
 FLAG_HOST_ONLY = 2
+COMBINE_AUTO, COMBINE_HOST, COMBINE_RCCL = 0, 1, 2
+
+
+def sum_partials(partials):
+    """(G, len) per-device partials -> their fixed-order sum (the multi-device context's host combine)."""
+    p = np.ascontiguousarray(partials, dtype=np.float64)
+    out = np.zeros(p.shape[1])
+    rc = lib().svsdf_sum_partials(_p(p), p.shape[0], p.shape[1], _p(out))
+    if rc:
+        raise SvsdfError(f"svsdf_sum_partials failed: {rc}")
+    return out
 
 
 def shard_plan(xyz, rank, world_size, flags=0):
@@ -289,7 +307,7 @@ class SvsdfContext:
 
     def __init__(self, shape="star", safety_hor=0.7, weight_p=60.0, rho=3.8,
                  poly_params=(0.0, 0.0, 0.0), polygon=None, head_state=None, tail_state=None,
-                 device=-1, rank=0, world_size=1, flags=0):
+                 device=-1, rank=0, world_size=1, flags=0, devices=None, combine=COMBINE_AUTO):
         self.L = lib()
         cfg = Config()
         self.L.svsdf_config_default(C.byref(cfg))
@@ -301,6 +319,11 @@ class SvsdfContext:
         cfg.head_state[:] = list(_colmajor(hs))
         cfg.tail_state[:] = list(_colmajor(ts))
         cfg.device, cfg.rank, cfg.world_size, cfg.flags = int(device), int(rank), int(world_size), int(flags)
+        if devices is not None and (len(devices) >= 2 or int(combine) == COMBINE_RCCL):    # in-process multi-GPU
+            cfg.n_devices = len(devices)
+            for k, d in enumerate(devices):
+                cfg.devices[k] = int(d)
+        cfg.combine = int(combine)
         self._poly = None
         if polygon is not None:
             self._poly = _f64(polygon).reshape(-1, 2).copy()
@@ -326,6 +349,11 @@ class SvsdfContext:
     def _chk(self, rc, what):
         if rc:
             raise SvsdfError(f"{what} failed ({rc}): " + self.L.svsdf_last_error_string(self.ctx).decode())
+
+    def set_conditions(self, head_state, tail_state):
+        hs, ts = _f64(head_state).reshape(3, 3), _f64(tail_state).reshape(3, 3)
+        self._chk(self.L.svsdf_set_conditions(self.ctx, _p(_colmajor(hs)), _p(_colmajor(ts))), "svsdf_set_conditions")
+        self.head_state, self.tail_state = hs, ts
 
     # ---- points ----
     def set_points(self, xyz):
@@ -473,6 +501,12 @@ class SvsdfContext:
 
     def sincos_mismatches(self, lo, hi, n):
         return int(self.L.svsdf_debug_sincos_mismatches(self.ctx, float(lo), float(hi), int(n)))
+
+    def shape_bound(self):
+        """(analytic R with sdf(q) >= |q| - R, largest |q| - sdf(q) sampled at creation)."""
+        o = np.zeros(2)
+        self._chk(self.L.svsdf_shape_bound(self.ctx, _p(o)), "svsdf_shape_bound")
+        return float(o[0]), float(o[1])
 
     def set_profiling(self, enable=True):
         self._chk(self.L.svsdf_set_profiling(self.ctx, int(bool(enable))), "svsdf_set_profiling")

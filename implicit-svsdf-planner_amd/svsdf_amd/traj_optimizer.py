@@ -47,6 +47,8 @@ class TrajOptimizer:
         self.initState = np.zeros((3, 3))
         self.finalState = np.zeros((3, 3))
         self.device = -1
+        self.devices = None            # list of >= 2 HIP ordinals: in-process multi-GPU context
+        self.combine = 0
         self._ctx = None
         self._points_dirty = True
 
@@ -60,6 +62,8 @@ class TrajOptimizer:
         self.poly_params = tuple(config.get("poly_params", self.poly_params))
         self.polygon = config.get("polygon", self.polygon)
         self.device = int(config.get("device", self.device))
+        self.devices = config.get("devices", self.devices)
+        self.combine = int(config.get("combine", self.combine))
         self._ctx = None
 
     def setPoints(self, xyz):
@@ -75,7 +79,10 @@ class TrajOptimizer:
         self.spatialDim = 3 * (int(N) - 1)
         self.initState = np.asarray(initS, dtype=np.float64).reshape(3, 3)
         self.finalState = np.asarray(finalS, dtype=np.float64).reshape(3, 3)
-        self._ctx = None
+        # the context (resident cloud, launch plan, persistent traj_duration SWM:376-385) survives
+        # successive optimisations; only the boundary states change
+        if self._ctx is not None:
+            self._ctx.set_conditions(self.initState, self.finalState)
 
     def _context(self):
         if self._ctx is None:
@@ -85,7 +92,8 @@ class TrajOptimizer:
             self._ctx = SvsdfContext(shape=sid, safety_hor=self.safety_hor, weight_p=self.weight_p,
                                      rho=self.rho, poly_params=self.poly_params, polygon=self.polygon,
                                      head_state=self.initState, tail_state=self.finalState,
-                                     device=self.device, rank=rank, world_size=ws)
+                                     device=self.device, rank=rank, world_size=ws,
+                                     devices=self.devices, combine=self.combine)
             self._points_dirty = True
         if self._points_dirty:
             self._ctx.set_points(self.parallel_points)
@@ -99,6 +107,11 @@ class TrajOptimizer:
         dev = torch.device("cuda", torch.cuda.current_device())
         # wrap the library's device buffer without copying
         t = _wrap_device_f64(ptr, n, dev)
+        if dist is not None and dist.get_backend() != "nccl":
+            # host-side collective (gloo): used to emulate several ranks on one GPU in tests; RCCL is the product path
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            return h.numpy()
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.cpu().numpy()

@@ -52,6 +52,7 @@ enum svsdf_shape_id {
 
 #define SVSDF_MAX_PIECES 64        /* MINCO pieces per trajectory handled on the device */
 #define SVSDF_MAX_POLY_VERTS 256   /* Polygon outline vertices */
+#define SVSDF_MAX_DEVICES 8        /* GPUs one context can drive (one xGMI node) */
 
 /* Error codes (0 = ok).  HIP runtime errors are returned as SVSDF_ERR_HIP_BASE + hipError_t. */
 enum svsdf_status {
@@ -60,6 +61,7 @@ enum svsdf_status {
   SVSDF_ERR_NO_DEVICE = 2,     /* no usable gfx950 device / HIP runtime unavailable */
   SVSDF_ERR_NO_POINTS = 3,     /* evaluate called before svsdf_set_points */
   SVSDF_ERR_NONFINITE = 4,     /* a non-finite value was produced on the device */
+  SVSDF_ERR_RCCL = 5,          /* RCCL unavailable / failed (SVSDF_COMBINE_RCCL) */
   SVSDF_ERR_HIP_BASE = 1000
 };
 
@@ -79,7 +81,22 @@ typedef struct svsdf_config {
   int rank, world_size;      /* point sharding: this context keeps points k with
                                 (sorted index k) % world_size == rank.  1 process per GPU. */
   int flags;                 /* SVSDF_FLAG_* */
+  /* In-process multi-GPU (the reference is ONE process: the LMBM shim keeps its callback and instance in
+   * file-static globals, src/utils/src/lmbm.cpp:4-6, and plan_manager.cpp:199 calls one optimizer): with
+   * n_devices >= 2 the context drives devices[0..n_devices) from one host thread per device; device k keeps
+   * stripe (rank * n_devices + k) of (world_size * n_devices) of the Morton order, every entry point fans the
+   * evaluation out, sums the n_devices (19N+1)-double partials and synchronises before returning.
+   * n_devices <= 1: the single device `device` (above).  A device may be listed more than once (several
+   * stripes on one GPU; host combine only). */
+  int n_devices;
+  int devices[SVSDF_MAX_DEVICES];
+  int combine;               /* SVSDF_COMBINE_*: how the per-device partials are summed */
 } svsdf_config;
+
+#define SVSDF_COMBINE_AUTO 0 /* = HOST (measured: DESIGN.md "Multi-GPU") */
+#define SVSDF_COMBINE_HOST 1 /* every device writes its partial to pinned host memory, fixed-order host sum */
+#define SVSDF_COMBINE_RCCL 2 /* ncclAllReduce(ncclDouble, ncclSum) over an in-process communicator
+                                (ncclCommInitAll), then one read-back; needs distinct devices */
 
 #define SVSDF_FLAG_DEFAULT 0
 #define SVSDF_FLAG_KEEP_INPUT_ORDER 1 /* do not Morton-sort the cloud at upload (debug) */
@@ -97,6 +114,10 @@ void svsdf_destroy(svsdf_ctx *ctx);
 void svsdf_config_default(svsdf_config *cfg);
 /* shape registry lookup as SWM:350-356 does it: stem of "shapes/star.obj" -> "star" -> id;
  * unknown stems give SVSDF_SHAPE_Polygon (the reference's fallback). */
+/* Boundary states only (first lines of TrajOptimizer::optimize_traj_lmbm, back_end_optimizer.cpp:13-19):
+ * keeps the context, the resident cloud, the launch plan and SweptVolumeManager's persistent
+ * traj_duration (SWM:376-385) across optimisations. */
+int svsdf_set_conditions(svsdf_ctx *ctx, const double head_state[9], const double tail_state[9]);
 int svsdf_shape_id_from_inputdata(const char *inputdata);
 const char *svsdf_shape_name(int shape_id);
 const char *svsdf_last_error_string(const svsdf_ctx *ctx); /* ctx may be NULL */
@@ -131,6 +152,9 @@ int svsdf_eval_penalty_partial(svsdf_ctx *ctx, int N, const double *coeffs, cons
                                double **d_partial, size_t *partial_len);
 int svsdf_accumulate_partial(svsdf_ctx *ctx, int N, const double *partial_host,
                              double *cost, double *gradT, double *gradC);
+/* Pure host: out[e] = partials[0][e] + partials[1][e] + ... in index order (the fixed-order sum the
+ * multi-device context applies to its per-device partials; `partials` = G rows of `len` doubles). */
+int svsdf_sum_partials(const double *partials, int G, size_t len, double *out);
 
 /* ---- the full optimizer callback --------------------------------------------------------------- */
 /* Same signature as lmbm_evaluate_t (src/utils/include/utils/lmbm.h:206-209); replaces
@@ -266,8 +290,19 @@ typedef struct svsdf_stats {
   unsigned int solve_launches;        /* k_solve launches of the last evaluation */
   unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
   unsigned long long culled_points;   /* main queries proven inactive (sdf > safety_hor) without a solve */
+  int gsip_bound_mode;                /* 0 = cheap chunk bound, 1 = full table scan per GSIP sample */
+  int bound_mode_decided;             /* 1 once the mode is fixed for this point set (after <= 1 evaluation) */
+  double bound_ratio;                 /* GSIP solves / samples of the deciding evaluation (rule: > 0.5 -> full) */
+  int n_devices;                      /* devices that took part (1 unless svsdf_config::n_devices > 1) */
+  int combine;                        /* SVSDF_COMBINE_* used by the last evaluation */
+  double combine_ms;                  /* host wall time from "all devices done" to "summed partial on the host" */
+  double setup_ms;                    /* host wall time of the last svsdf_set_points (sort + upload) */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
+/* Shape bound used by the exact scan pruning and the exact cull: out2[0] = R with sdf_shape(q) >= |q| - R
+ * (analytic circumradius of the shape + |offset|, Shape.hpp:281-294 / :531-1476), out2[1] = the largest
+ * |q| - sdf_shape(q) found on a polar grid out to 60 m at context creation (self-check: <= out2[0]). */
+int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]);
 /* Per-launch HIP-event timing of the dominant (argmin refine) kernel on the library's own
  * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms. */
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable);

@@ -20,7 +20,12 @@
 
 #include "svsdf_c.h"
 
-#if defined(__has_include)
+// Eigen is optional.  SVSDF_EIGEN_HEADER lets a build point at another header providing Eigen::VectorXd /
+// Eigen::MatrixX3d with data() and size() (tests/cpp/mini_eigen.hpp: this image has no Eigen).
+#if defined(SVSDF_EIGEN_HEADER)
+#include SVSDF_EIGEN_HEADER
+#define SVSDF_HAVE_EIGEN 1
+#elif defined(__has_include)
 #if __has_include(<Eigen/Core>)
 #include <Eigen/Core>
 #define SVSDF_HAVE_EIGEN 1
@@ -41,6 +46,8 @@ class TrajOptimizerHip {
   std::vector<double> polygon_xy;  // optional outline for the Polygon fallback
   int device = -1;
   int rank = 0, world_size = 1;
+  std::vector<int> devices;        // >= 2 entries: in-process multi-GPU (svsdf_config::n_devices / devices)
+  int combine = SVSDF_COMBINE_AUTO;
 
   // --- optimisation state (BEO:44-60) ---
   int pieceN = 0, temporalDim = 0, spatialDim = 0;
@@ -65,9 +72,12 @@ class TrajOptimizerHip {
     pieceN = N; temporalDim = N; spatialDim = 3 * (N - 1);
     std::memcpy(initState, initS, sizeof(initState));
     std::memcpy(finalState, finalS, sizeof(finalState));
-    svsdf_destroy(ctx_);
-    ctx_ = nullptr;
+    // the context (resident cloud, launch plan, SweptVolumeManager's persistent traj_duration SWM:376-385)
+    // survives successive optimisations; only the boundary states change
+    if (ctx_ && svsdf_set_conditions(ctx_, initState, finalState) != SVSDF_OK) { svsdf_destroy(ctx_); ctx_ = nullptr; }
   }
+  // after changing a Config-derived member (shape, weights, devices): rebuild the context on next use
+  void resetContext() { svsdf_destroy(ctx_); ctx_ = nullptr; }
 
   // static double costFunctionLmbmParallel(void *ptr, const double *x, double *g, const int n)
   static double costFunctionLmbmParallel(void *ptr, const double *x_variable, double *g, const int n) {
@@ -138,6 +148,11 @@ class TrajOptimizerHip {
       std::memcpy(cfg.head_state, initState, sizeof(initState));
       std::memcpy(cfg.tail_state, finalState, sizeof(finalState));
       cfg.device = device; cfg.rank = rank; cfg.world_size = world_size;
+      cfg.combine = combine;
+      if (devices.size() >= 2 && devices.size() <= SVSDF_MAX_DEVICES) {
+        cfg.n_devices = (int)devices.size();
+        for (std::size_t k = 0; k < devices.size(); ++k) cfg.devices[k] = devices[k];
+      }
       cfg.polygon_nverts = (int)(polygon_xy.size() / 2);
       cfg.polygon_xy = polygon_xy.empty() ? nullptr : polygon_xy.data();
       ctx_ = svsdf_create(&cfg);

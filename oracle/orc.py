@@ -31,7 +31,8 @@ def build(force=False):
     src = os.path.join(_HERE, "svsdf_oracle.c")
     hdr = os.path.join(_HERE, "svsdf_oracle.h")
     stale = (not os.path.exists(so)) or any(
-        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr))
+        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so)
+        for f in (src, hdr, os.path.join(_HERE, "Makefile")))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
     return so

@@ -46,12 +46,62 @@ def test_cpp_mirror_matches_ctypes_path(built):
                                  head_state=w["head_state"], tail_state=w["tail_state"], device=0)
     ctx.set_points(w["points"])
     f, g = ctx.lmbm_evaluate(x)
-    assert abs(vals[0] - f) <= 1e-12 * abs(f)
-    np.testing.assert_allclose(vals[1:4], ctx.last_costs(), rtol=1e-12)
-    np.testing.assert_allclose(vals[4:], g, rtol=1e-9, atol=1e-9)
+    assert vals[0] == f
+    np.testing.assert_array_equal(vals[1:4], ctx.last_costs())
+    np.testing.assert_array_equal(vals[4:], g)
     # optimize_traj_lmbm through the mirror == optimize_traj through ctypes (same library, same driver)
     xo, fo, rc, it, _ = ctx.optimize_traj(x, max_iterations=15)
     assert int(opt[0]) == (1 if rc == 0 else rc) and int(opt[1]) == it
-    assert abs(float(opt[2]) - fo) <= 1e-8 * abs(fo)   # LDS-atomic sum order differs run to run (~1e-12 per call)
-    np.testing.assert_allclose([float(v) for v in opt[4:]], xo, rtol=0, atol=1e-6)
+    assert abs(float(opt[2]) - fo) <= 1e-12 * abs(fo)   # evaluations are bit-reproducible (no FP atomics)
+    np.testing.assert_allclose([float(v) for v in opt[4:]], xo, rtol=0, atol=1e-12)
     assert fo < f
+
+
+# ---- the lbfgs::lbfgs_evaluate_t adapter (lbfgs.hpp:213-216; north_star "preserves the lbfgs_optimize callback
+# signature").  The image has no Eigen: the mirror is compiled against tests/cpp/mini_eigen.hpp (data()/size() only).
+ADAPTER = os.path.join(ROOT, "tests", "cpp", "lbfgs_adapter_driver")
+
+
+def _build_adapter():
+    src = os.path.join(ROOT, "tests", "cpp", "lbfgs_adapter_driver.cpp")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-DSVSDF_EIGEN_HEADER=\"mini_eigen.hpp\"",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"), src, "-o", ADAPTER,
+           "-L", PKG, "-lsvsdf_hip", "-Wl,-rpath," + PKG]
+    subprocess.check_call(cmd)
+    return ADAPTER
+
+
+def test_lbfgs_adapter_compiles_with_the_reference_callback_type(built):
+    exe = _build_adapter()
+    assert subprocess.check_output([exe, "--compile-only"]).decode().split() == ["1"]
+
+
+@pytest.mark.gpu
+def test_lbfgs_adapter_matches_ctypes_path(built):
+    import svsdf_amd
+    from svsdf_amd import workload
+    exe = _build_adapter()
+    w = workload.make("C1", P=700, minco=svsdf_amd.minco_coeffs)
+    N = len(w["T"])
+    x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+    col = lambda m: " ".join(repr(float(v)) for v in np.asfortranarray(m).ravel(order="F"))
+    inp = f"shapes/star.obj {w['safety_hor']!r} {w['weight_p']!r} {w['rho']!r} {N} {len(w['points'])}\n"
+    inp += col(w["head_state"]) + "\n" + col(w["tail_state"]) + "\n"
+    inp += " ".join(repr(float(v)) for v in x) + "\n"
+    inp += " ".join(repr(float(v)) for v in w["points"].ravel()) + "\n"
+    inp += col(w["coeffs"]) + "\n" + " ".join(repr(float(v)) for v in w["T"]) + "\n"
+    out = subprocess.run([exe], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split()
+    vals = np.array([float(v) for v in out])
+    n = len(x)
+    ctx = svsdf_amd.SvsdfContext(shape="star", safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
+                                 head_state=w["head_state"], tail_state=w["tail_state"], device=0)
+    ctx.set_points(w["points"])
+    f, g = ctx.lmbm_evaluate(x)
+    assert vals[0] == f                                   # bit-reproducible evaluation: exact equality
+    assert vals[1] == vals[2] == ctx.last_costs()[0]      # p_cost == cost_pos (mid_end.cpp:54-60 reads it)
+    np.testing.assert_array_equal(vals[3:3 + n], g)
+    c, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"], cost0=0.25, gradT0=np.ones(N), gradC0=np.zeros((6 * N, 3)))
+    rest = vals[3 + n:]
+    assert rest[0] == c
+    np.testing.assert_array_equal(rest[1:1 + N], gT)
+    np.testing.assert_array_equal(rest[1 + N:], np.asfortranarray(gC).ravel(order="F"))

@@ -194,6 +194,27 @@ def test_baseline_sizes_match_oracle(built, config, full, evals_pp):
           f"gradC rel {_rel(gC, ogC):.2e}, gradT rel {_rel(gT, ogT):.2e}")
 
 
+@pytest.mark.parametrize("config,evals_pp", [("C2", 3000), ("C3", 5000), ("C4", 5000)])
+def test_map_distribution_matches_oracle(built, config, evals_pp):
+    """Second point distribution of SURVEY.md §8(d): uniform over the demo map extent [0, 30.5] x [0, 75] m (most
+    points far from the path: the exact cull carries the evaluation).  Same gates as the corridor cloud."""
+    P = max(4000, min(200000, _budget_points(evals_pp)))
+    w, ctx, o = _mk(config, P, dist="map")
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    st = ctx.stats()
+    ocost, ogT, ogC, osdf, ots, _ = o.penalty(w["points"], nthreads=NT, sum_mode=1, per_point=True)
+    flips = np.abs(ts - ots) > 1e-6
+    assert flips.mean() <= 2e-3, (int(flips.sum()), P)
+    assert np.abs(sdf[~flips] - osdf[~flips]).max() <= 1e-7
+    assert st["interior_points"] == o.counters()["interior_points"]
+    assert st["culled_points"] > 0.3 * P
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost), (cost, ocost)
+    assert _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5, (_rel(gC, ogC), _rel(gT, ogT))
+    print(f"{config} map: P = {P}, flips {int(flips.sum())}, culled {st['culled_points']}, cost rel "
+          f"{abs(cost - ocost) / abs(ocost):.2e}, gradC rel {_rel(gC, ogC):.2e}, gradT rel {_rel(gT, ogT):.2e}")
+
+
 def test_differential_fuzz(built):
     """tools/fuzz_parity.py: 60 random (shape, shape offset, 1-6 piece trajectory, safety margin, 400 points)
     cases, HIP vs oracle.  Cost must agree to 1e-7 everywhere.  The gradient gate is 1e-4 here, not 1e-5: these
