@@ -530,7 +530,7 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
       if (rc) return rc;
       ctx->block_partials_cap = (size_t)grid * plen;
     }
-    const size_t lds = ((size_t)traj_lds_doubles(N) + plen) * sizeof(double);
+    const size_t lds = ((size_t)traj_lds_doubles(N) + (kBlock / 64) * plen) * sizeof(double);  // one accumulator row per wave
     hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
                        (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
                        ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite);
@@ -839,10 +839,34 @@ struct RcclApi {
   const char *(*GetErrorString)(int) = nullptr;
   bool load() {
     if (h) return true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (h) break;
+    // RCCL must come from the same ROCm tree as the HIP/HSA runtime this library is bound to: its init dlopen()s
+    // "libhsa-runtime64.so" by file name, and a copy from another tree (PyTorch-ROCm ships its own under torch/lib)
+    // is a second, uninitialised HSA instance ("no ROCm-capable device").  So: the librccl next to our libamdhip64
+    // first, then whatever the process already holds, then the default search path.
+    {
+      Dl_info di;
+      if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t k = dir.rfind('/');
+        if (k != std::string::npos) {
+          dir.resize(k);
+          for (const char *name : {"/librccl.so.1", "/librccl.so"}) {
+            h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+          }
+        }
+      }
     }
+    if (!h)
+      for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+      }
+    if (!h)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+      }
     if (!h) return false;
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -1013,6 +1037,10 @@ svsdf_ctx *create_group(const svsdf_config *cfg, int ndev) {
     if (!distinct) return bail("svsdf_create: SVSDF_COMBINE_RCCL needs distinct devices (one communicator rank per GPU)");
     if (!g_rccl.load()) return bail("svsdf_create: librccl.so could not be loaded (SVSDF_COMBINE_RCCL)");
     g->comms.assign(G, nullptr);
+    {
+      const hipError_t stale = hipGetLastError();   // RCCL's init treats any pending (sticky-until-read) HIP error as its own
+      if (stale != hipSuccess && std::getenv("SVSDF_DEBUG")) std::fprintf(stderr, "[svsdf] cleared pending HIP error before ncclCommInitAll: %s\n", hipGetErrorString(stale));
+    }
     const int e = g_rccl.CommInitAll(g->comms.data(), G, cfg->devices);
     if (e) { g->comms.clear(); return bail(std::string("svsdf_create: ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error")); }
     g->d_red.assign(G, nullptr);

@@ -866,7 +866,10 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
 // ---------------------------------------------------------------------------------------------
 // LP lanes per point (8 or 32): the early rounds have 2 and 6 samples, the later ones 18-21; a
 // point with more samples than lanes is handled in ceil(n / LP) passes.
-constexpr int kRoundBlock = 1024;
+#ifndef SVSDF_ROUND_BLOCK
+#define SVSDF_ROUND_BLOCK 1024
+#endif
+constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
 template <int SHAPE, int LP, bool FULL>
 __global__ void __launch_bounds__(kRoundBlock)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
