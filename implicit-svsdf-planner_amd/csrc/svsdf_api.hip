@@ -117,6 +117,7 @@ struct svsdf_ctx {
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
+  bool block_env = false;      // env SVSDF_BLOCK pins the solve kernel's block size (default: by LDS footprint)
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
@@ -261,8 +262,12 @@ void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long lo
                      double *out_t, BatchCtl *ctl, int work_idx, double cull_thresh) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
-  const int blk = ctx->block;
   const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N)) * sizeof(double);
+  // Every block stages the pose table + chunk bounds + trajectory into LDS (13 KB at 16 pieces x 2.5 s, 24 KB at 32):
+  // with one wave per block that caps the CU at 160 KB / lds waves -- 6 at C3, half of what the kernel's 141 VGPRs
+  // allow (3 waves per SIMD) -- so the block grows until LDS no longer binds (measured at C3: 10.7 -> 9.2 ms).
+  int blk = ctx->block;
+  if (!ctx->block_env) blk = (lds * 12 <= 160 * 1024) ? 64 : (lds * 6 <= 160 * 1024) ? 128 : 256;
   const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
@@ -474,8 +479,8 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
     // evaluation tells how many solves this launch will hold.  Few solves = a latency-bound launch (<= ~1 wave per
     // SIMD): widen the groups to shorten the dependent chain; many solves = throughput: keep the shard's width even
     // in late iterations.  Any width gives the same bits, so a wrong guess only costs time.
-    if (!ctx->G_env && !ctx->G_late_env && ctx->have_prev_nsolve && ctx->nbatch == 1) {
-      const long long n = ctx->prev_nsolve[it];
+    if (!ctx->G_env && !ctx->G_late_env && ctx->have_prev_nsolve) {
+      const long long n = ctx->prev_nsolve[it];   // summed over the batches: they run this iteration concurrently
       G = ctx->G;
       if (n < ctx->wide32_below) G = std::max(G, 32);
       else if (n < ctx->wide16_below) G = std::max(G, 16);
@@ -509,8 +514,8 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     QuerySet qm{};
     qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
     qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
-    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0,
-                 (allow_cull && ctx->cull && ctx->cull_ok) ? ctx->cfg.safety_hor + 1e-9 : std::numeric_limits<double>::infinity());
+    const double cull_thresh = (allow_cull && ctx->cull && ctx->cull_ok) ? ctx->cfg.safety_hor + 1e-9 : std::numeric_limits<double>::infinity();
+    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0, cull_thresh);
     launch_classify(ctx, st, b);
     launch_round(ctx, st, b, 0);
   }
@@ -581,12 +586,30 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
     ctx->stats.device_ms = ms;
+    // k_solve time of the evaluation: the point batches run concurrently on their own streams, so the launches'
+    // [start, stop] intervals (device clock, relative to the evaluation's first event) are merged -- solve_ms is the
+    // time during which at least one k_solve launch was executing, solve_ms_sum the plain sum of the launch durations
+    // (what a kernel trace adds up)
     double sum = 0.0;
+    std::vector<std::pair<float, float>> iv;
     for (const auto &pr : ctx->refine_events) {
-      float m = 0.f;
-      if (hipEventElapsedTime(&m, ctx->ev_pool[pr.first], ctx->ev_pool[pr.second]) == hipSuccess) sum += m;
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, ctx->ev_pool[0], ctx->ev_pool[pr.first]) == hipSuccess &&
+          hipEventElapsedTime(&b, ctx->ev_pool[0], ctx->ev_pool[pr.second]) == hipSuccess && b >= a) {
+        iv.emplace_back(a, b);
+        sum += b - a;
+      }
     }
-    ctx->stats.solve_ms = sum;
+    std::sort(iv.begin(), iv.end());
+    double uni = 0.0;
+    float cur_a = 0.f, cur_b = -1.f;
+    for (const auto &x : iv) {
+      if (x.first > cur_b) { if (cur_b >= cur_a) uni += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
+      else cur_b = std::max(cur_b, x.second);
+    }
+    if (cur_b >= cur_a) uni += cur_b - cur_a;
+    ctx->stats.solve_ms = uni;
+    ctx->stats.solve_ms_sum = sum;
   }
 #ifdef SVSDF_TIMING
   if (std::getenv("SVSDF_DUMP_TIMING")) {
@@ -604,6 +627,8 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   if (st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
 }
+
+int set_batches(svsdf_ctx *ctx, int nb);   // below
 
 void fill_mode_stats(svsdf_ctx *ctx) {
   ctx->stats.gsip_bound_mode = ctx->ub_full ? 1 : 0;
@@ -663,6 +688,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_full = ctx->ub_ratio > ctx->ub_threshold;
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
+    if (ctx->ub_full && ctx->want_batches == 0 && ctx->P >= 400000) rc = set_batches(ctx, 4);
   }
   fill_mode_stats(ctx);
   ctx->h_partial = ctx->h_out;
@@ -762,6 +788,29 @@ void shard_plan(const double *xyz, size_t P, int rk, int ws, int flags, std::vec
   stripe_of(order, rk, ws, out);
 }
 
+// Split the resident shard into nb contiguous batches of the sorted cloud, each running the whole launch chain on its
+// own stream.  Large shards in the full-scan GSIP mode use 4: that chain alternates k_round (table scans) and k_solve
+// launches of similar weight, ~10 dependent pairs, each ending in a tail where the chip drains; another batch's
+// kernels fill those tails (1 M points: sdHorseshoe / 32 pieces 9.3 -> 8.6 ms, sdHeart 11.3 -> 10.5 ms).  In the
+// cheap-bound mode (star) the solves dominate and splitting buys nothing (12.0 vs 12.0-12.7 ms); small shards are
+// latency-bound chains, splitting only adds launches.  Any split gives the same bits.
+int set_batches(svsdf_ctx *ctx, int nb) {
+  nb = std::max(1, std::min(nb, kMaxBatches));
+  const size_t Ps = ctx->P;
+  ctx->nbatch = nb;
+  std::vector<BatchCtl> hc(kMaxBatches);
+  std::memset(hc.data(), 0, sizeof(BatchCtl) * kMaxBatches);
+  for (int b = 0; b < nb; ++b) {
+    const size_t s = Ps * (size_t)b / nb, e = Ps * (size_t)(b + 1) / nb;
+    ctx->bstart[b] = (int)s;
+    ctx->bcount[b] = (int)(e - s);
+    hc[b].start = (int)s;
+    hc[b].count = (int)(e - s);
+  }
+  HIPCHK(hipMemcpy(ctx->d_ctl, hc.data(), sizeof(BatchCtl) * kMaxBatches, hipMemcpyHostToDevice));
+  return SVSDF_OK;
+}
+
 // Upload this context's stripe (ctx->shard_idx, already planned) of the host cloud.
 int upload_shard(svsdf_ctx *ctx, const double *xyz) {
   HIPCHK(hipSetDevice(ctx->device));
@@ -782,10 +831,10 @@ int upload_shard(svsdf_ctx *ctx, const double *xyz) {
     HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
   }
-  // batches: contiguous ranges of the sorted shard, pipelined on separate streams
-  int nb = ctx->want_batches > 0 ? ctx->want_batches : 1;  // multi-stream batches (SVSDF_BATCHES) measured inconsistent across boxes
-  nb = std::max(1, std::min(nb, kMaxBatches));
-  ctx->nbatch = nb;
+  // batches: contiguous ranges of the sorted shard, pipelined on separate streams (one until the GSIP bound mode is
+  // known, see set_batches)
+  int rcb = set_batches(ctx, ctx->want_batches > 0 ? ctx->want_batches : 1);
+  if (rcb) return rcb;
   // lanes per query: an evaluation is a chain of ~10 dependent solve launches, each a chain of ~100 dependent
   // group steps.  Small shards cannot fill the GPU and are pure latency: wide groups shorten the chains
   // (32 lanes: a whole halving ladder / scan layer per step).  Large shards are throughput: narrow groups waste
@@ -798,16 +847,6 @@ int upload_shard(svsdf_ctx *ctx, const double *xyz) {
     ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
   }
-  std::vector<BatchCtl> hc(kMaxBatches);
-  std::memset(hc.data(), 0, sizeof(BatchCtl) * kMaxBatches);
-  for (int b = 0; b < nb; ++b) {
-    const size_t s = Ps * (size_t)b / nb, e = Ps * (size_t)(b + 1) / nb;
-    ctx->bstart[b] = (int)s;
-    ctx->bcount[b] = (int)(e - s);
-    hc[b].start = (int)s;
-    hc[b].count = (int)(e - s);
-  }
-  HIPCHK(hipMemcpy(ctx->d_ctl, hc.data(), sizeof(BatchCtl) * kMaxBatches, hipMemcpyHostToDevice));
   return SVSDF_OK;
 }
 
@@ -886,6 +925,7 @@ void merge_stats(svsdf_ctx *ctx) {
     t.gsip_samples += a.gsip_samples; t.sdf_evals += a.sdf_evals; t.scan_evals += a.scan_evals;
     t.culled_points += a.culled_points;
     t.device_ms = std::max(t.device_ms, a.device_ms); t.solve_ms = std::max(t.solve_ms, a.solve_ms);
+    t.solve_ms_sum = std::max(t.solve_ms_sum, a.solve_ms_sum);
     t.solve_launches = std::max(t.solve_launches, a.solve_launches);
     t.gsip_iterations = std::max(t.gsip_iterations, a.gsip_iterations);
     t.gsip_bound_mode = std::max(t.gsip_bound_mode, a.gsip_bound_mode);
@@ -1103,6 +1143,13 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     h->host_only = true;
     return h;
   }
+  // Large shards run as 4 point batches on their own streams plus the main stream; the HIP runtime maps streams onto
+  // GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue serialise (measured with the runtime
+  // bundled with PyTorch-ROCm 7.0: 4 batches 10.2 ms vs 8.7 ms with 8 queues).  Only effective if the runtime has not
+  // been initialised yet by the host process (a Python host sets it before importing torch, see bench.py); never
+  // overrides a value the user chose.
+  static const int queues_hint = setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  (void)queues_hint;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_last_error = "svsdf_create: no HIP device (this library has no CPU fallback)";
@@ -1160,7 +1207,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
   if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_late = g; ctx->G_late_env = g; } }
   if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
-  if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; }
+  if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; ctx->block_env = true; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
   if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) { ctx->delta_all_iter = std::atoi(e); ctx->all_iter_env = true; }

@@ -60,7 +60,8 @@ class Stats(C.Structure):
                 ("scan_evals", C.c_ulonglong), ("device_ms", C.c_double), ("solve_ms", C.c_double),
                 ("solve_launches", C.c_uint), ("gsip_iterations", C.c_uint), ("culled_points", C.c_ulonglong),
                 ("gsip_bound_mode", C.c_int), ("bound_mode_decided", C.c_int), ("bound_ratio", C.c_double),
-                ("n_devices", C.c_int), ("combine", C.c_int), ("combine_ms", C.c_double), ("setup_ms", C.c_double)]
+                ("n_devices", C.c_int), ("combine", C.c_int), ("combine_ms", C.c_double), ("setup_ms", C.c_double),
+                ("solve_ms_sum", C.c_double)]
 
 
 class SvsdfError(RuntimeError):

@@ -286,7 +286,7 @@ typedef struct svsdf_stats {
   unsigned long long sdf_evals;       /* SDF-at-time evaluations executed on the device */
   unsigned long long scan_evals;      /* of which layer-1 table evaluations */
   double device_ms;                   /* HIP-event time of the whole device pipeline (profiling on) */
-  double solve_ms;                    /* HIP-event time summed over the k_solve launches (profiling on) */
+  double solve_ms;                    /* HIP-event time during which >= 1 k_solve launch was executing (profiling on) */
   unsigned int solve_launches;        /* k_solve launches of the last evaluation */
   unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
   unsigned long long culled_points;   /* main queries proven inactive (sdf > safety_hor) without a solve */
@@ -297,6 +297,8 @@ typedef struct svsdf_stats {
   int combine;                        /* SVSDF_COMBINE_* used by the last evaluation */
   double combine_ms;                  /* host wall time from "all devices done" to "summed partial on the host" */
   double setup_ms;                    /* host wall time of the last svsdf_set_points (sort + upload) */
+  double solve_ms_sum;                /* plain sum of the k_solve launch durations (solve_ms merges the intervals of
+                                         launches that ran concurrently on different streams) (profiling on) */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 /* Shape bound used by the exact scan pruning and the exact cull: out2[0] = R with sdf_shape(q) >= |q| - R
