@@ -256,7 +256,7 @@ def main():
             raise SystemExit("--inprocess is a single-process mode (do not launch it with torchrun)")
         devices = [int(v) for v in a.devices.split(",")] if a.devices else list(range(a.gpus))
         n_gpus = len(devices)
-        if n_gpus < 2:
+        if n_gpus < 2 and a.combine != "rccl":   # (one device + rccl: a 1-rank communicator, measures the collective's fixed cost)
             devices = None
     multi = n_gpus > 1
     name = a.config or ("C4" if multi else "C3")
@@ -356,8 +356,9 @@ def main():
                               "sdf_evals_per_step": evals_all / a.steps, "layer1_evals_per_step": scan_all / a.steps,
                               "flop_per_eval_nominal": FLOP_PER_EVAL}},
     }
-    if multi:
+    if multi or devices is not None or ar_ms is not None:
         res["combine"] = {"ms_allreduce": ar_ms, "ms_combine_inprocess": combine_ms if a.inprocess else None,
+                          "mode": ["host", "host", "rccl"][last["combine"]] if a.inprocess else "torch.distributed",
                           "note": "ms_allreduce: RCCL all-reduce of 19N+1 doubles alone (launch + sync, torchrun path); "
                                   "ms_combine_inprocess: host time from 'all devices done' to 'summed partial on the host'"}
     # release the headline workload before the sub-runs
@@ -373,9 +374,17 @@ def main():
             cb = cpu_baseline(wn, a.cpu_seconds / 2)
             res["north_star"]["cpu_baseline"] = cb
             res["north_star"]["speedup_vs_cpu_baseline"] = res["north_star"]["value"] / cb["value"]
-    print(json.dumps(res))
     if tdist is not None:
         tdist.destroy_process_group()
+    # RCCL writes a version banner to the C stdio buffer at communicator creation: push it out first so that the
+    # JSON line is the LAST line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,16 +1,27 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): bench + rocprofv3 kernel stats + PMC passes of the same command.
-# usage: tools/profile_round.sh <tag>   -> writes gpurun_out/<tag>_*
+# Run on the GPU box (through gpurun): bench line + rocprofv3 kernel stats + PMC passes of the same command.
+# usage: tools/profile_round.sh <tag> [config]   -> writes gpurun_out/<tag>_*   (config: C3 default, NS, C2 ...)
 set -u
-TAG=${1:-r01_v4}
+TAG=${1:-r02}
+CFG=${2:-C3}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python -u $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-timeout 600 python -u $ROOT/bench.py > $OUT/${TAG}_bench_C2.json 2> $OUT/${TAG}_bench.err
+BENCH="python -u $ROOT/bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
+timeout 600 $BENCH > $OUT/${TAG}_bench_${CFG}_short.json 2> $OUT/${TAG}_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- $BENCH > $OUT/${TAG}_kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_f -o f -- $BENCH > $OUT/${TAG}_pmc_f.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_w -o w -- $BENCH > $OUT/${TAG}_pmc_w.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_s -o s -- $BENCH > $OUT/${TAG}_pmc_s.log 2>&1
-find $OUT -name '*.csv' | head -30
+# summaries small enough to come back; the raw traces stay on the box
+KS=$(find $OUT/${TAG}_kt -name '*kernel_stats.csv' | head -1); cp $KS $OUT/${TAG}_bench_${CFG}_kernel_stats.csv
+F=$(find $OUT/${TAG}_pmc_f -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/${TAG}_pmc_w -name '*counter_collection.csv' | head -1)
+S=$(find $OUT/${TAG}_pmc_s -name '*counter_collection.csv' | head -1)
+# evaluations per profiled run: 2 settle + 1 warm-up + 5 timed + 5 event-profiled + 2 full-callback passes (1 + 5 each... see bench.py)
+python $ROOT/tools/pmc_summary.py $F $W $S ${3:-25} "rocprofv3 PMC summary, bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-extras, 1x MI355X, $TAG" > $OUT/${TAG}_bench_${CFG}_pmc_summary.txt
+KT=$(find $OUT/${TAG}_kt -name '*kernel_trace.csv' | head -1)
+python $ROOT/tools/timeline.py $KT 6 > $OUT/${TAG}_bench_${CFG}_timeline.txt 2>&1
+rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_s
+tail -c 300 $OUT/${TAG}_bench_${CFG}_short.json
