@@ -5,6 +5,7 @@
 // addSaftyPenaOnSweptVolumeParallelTrueSDF (BEO:774-869); see include/svsdf_c.h for the
 // per-entry-point citations.  No CPU fallback: without a HIP device every compute entry fails.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <dlfcn.h>
 
@@ -124,7 +125,8 @@ struct svsdf_ctx {
   bool ub_env = false;         // env SVSDF_UB_FULL=0/1 pins the mode, otherwise run_pipeline decides after one evaluation
   int ub_tune = 0;             // evaluations since the point set changed that took part in the decision (0 or 1)
   double ub_ratio = 0.0;       // GSIP solves / GSIP samples of the deciding (cheap-bound) evaluation
-  double ub_threshold = 0.5;   // env SVSDF_UB_RATIO
+  double ub_threshold = 0.5;   // env SVSDF_UB_RATIO (analytic shapes; Polygon 0.2)
+  bool ub_thr_env = false;
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
   int G_env = 0, G_late_env = 0;
@@ -685,7 +687,10 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
     const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
     ctx->ub_ratio = ctx->stats.gsip_samples ? (double)gs / (double)ctx->stats.gsip_samples : 0.0;
-    ctx->ub_full = ctx->ub_ratio > ctx->ub_threshold;
+    // Polygon: an SDF evaluation costs ~10 x an analytic shape's (one pass over the outline per evaluation), a table
+    // scan proportionally less of a solve, so scanning pays from a lower ratio (C5, 1 M points: 55.5 -> 48.3 ms)
+    const double thr = ctx->ub_thr_env ? ctx->ub_threshold : (ctx->cfg.shape_id == SVSDF_SHAPE_Polygon ? 0.2 : ctx->ub_threshold);
+    ctx->ub_full = ctx->ub_ratio > thr;
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
     if (ctx->ub_full && ctx->want_batches == 0 && ctx->P >= 400000) rc = set_batches(ctx, 4);
@@ -811,26 +816,77 @@ int set_batches(svsdf_ctx *ctx, int nb) {
   return SVSDF_OK;
 }
 
-// Upload this context's stripe (ctx->shard_idx, already planned) of the host cloud.
-int upload_shard(svsdf_ctx *ctx, const double *xyz) {
+// Plan and upload this context's stripe of the cloud ON THE DEVICE: d_xyz (AoS, P x 3 doubles, on ctx's device) ->
+// bounding box -> Morton keys -> radix sort (hipcub, all 64 bits of (Morton code << 32 | input index): the same
+// order as the host planner's stable sort by Morton code; a partial bit range [32, 64) came back unsorted) ->
+// gather of stripe (rk, ws) into the SoA arrays + original indices.  Same key formula as the host planner
+// (svsdf_shard_plan), so both give the same order (tests/test_points_upload_gpu.py).  1 M points: ~2 ms on the
+// device (+ ~4 ms PCIe when the cloud comes from host memory) against 29 ms for round 1's host radix sort.
+int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, int ws) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipDeviceSynchronize());
-  const size_t Ps = ctx->shard_idx.size();
+  ws = std::max(1, ws);
+  const size_t Ps = (P > (size_t)rk) ? (P - (size_t)rk + (size_t)ws - 1) / (size_t)ws : 0;
   if (Ps * kMaxSlots > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard (max ~89M)");
-  std::vector<double> hx(Ps), hy(Ps);
-  for (size_t j = 0; j < Ps; ++j) {
-    hx[j] = xyz[3 * ctx->shard_idx[j]];
-    hy[j] = xyz[3 * ctx->shard_idx[j] + 1];
-    if (!std::isfinite(hx[j]) || !std::isfinite(hy[j])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite query point");
+  ctx->shard_idx.assign(Ps, 0ll);
+  int rc = alloc_point_buffers(ctx, Ps);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  if (P > 0) {
+    const unsigned grid = (unsigned)std::min<size_t>((P + kBlock - 1) / kBlock, 1024);
+    double *d_part = nullptr;
+    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+    long long *d_idx = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() {
+      for (void *q : {(void *)d_part, (void *)d_keys, (void *)d_keys2, (void *)d_idx, d_tmp})
+        if (q) (void)hipFree(q);
+    };
+#define UPCHK(expr)                                                                                                  \
+  do {                                                                                                               \
+    hipError_t e_ = (expr);                                                                                          \
+    if (e_ != hipSuccess) { cleanup(); return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+  } while (0)
+    UPCHK(hipMalloc((void **)&d_part, (size_t)grid * 4 * sizeof(double)));
+    UPCHK(hipMalloc((void **)&d_keys, P * sizeof(unsigned long long)));
+    UPCHK(hipMalloc((void **)&d_keys2, P * sizeof(unsigned long long)));
+    UPCHK(hipMalloc((void **)&d_idx, std::max<size_t>(Ps, 1) * sizeof(long long)));
+    UPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_points_bbox, dim3(grid), dim3(kBlock), 0, st, d_xyz, P, d_part, ctx->d_nonfinite);
+    std::vector<double> hp((size_t)grid * 4);
+    int bad = 0;
+    UPCHK(hipMemcpyAsync(hp.data(), d_part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    UPCHK(hipMemcpyAsync(&bad, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+    UPCHK(hipStreamSynchronize(st));
+    if (bad) { cleanup(); return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite query point"); }
+    double xmin = hp[0], xmax = hp[1], ymin = hp[2], ymax = hp[3];
+    for (unsigned b = 1; b < grid; ++b) {
+      xmin = std::min(xmin, hp[4 * b]); xmax = std::max(xmax, hp[4 * b + 1]);
+      ymin = std::min(ymin, hp[4 * b + 2]); ymax = std::max(ymax, hp[4 * b + 3]);
+    }
+    const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
+    const int keep = ((ctx->cfg.flags & SVSDF_FLAG_KEEP_INPUT_ORDER) || P <= 1) ? 1 : 0;
+    hipLaunchKernelGGL(k_points_keys, dim3(grid), dim3(kBlock), 0, st, d_xyz, P, xmin, ymin, ext, keep, d_keys);
+    const unsigned long long *sorted = d_keys;
+    if (!keep) {
+      size_t tmp_bytes = 0;
+      UPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)P, 0, 64, st));
+      UPCHK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+      UPCHK(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_keys2, (int)P, 0, 64, st));
+      sorted = d_keys2;
+    }
+    if (Ps > 0) {
+      const unsigned g2 = (unsigned)std::min<size_t>((Ps + kBlock - 1) / kBlock, 1024);
+      hipLaunchKernelGGL(k_points_gather, dim3(g2), dim3(kBlock), 0, st, d_xyz, sorted, P, rk, ws, Ps, ctx->d_px, ctx->d_py, d_idx);
+      UPCHK(hipMemcpyAsync(ctx->shard_idx.data(), d_idx, Ps * sizeof(long long), hipMemcpyDeviceToHost, st));
+    }
+    UPCHK(hipStreamSynchronize(st));
+    UPCHK(hipGetLastError());
+#undef UPCHK
+    cleanup();
   }
   ctx->P = Ps;
   ctx->points_set = true;
-  int rc = alloc_point_buffers(ctx, Ps);
-  if (rc) return rc;
-  if (Ps) {
-    HIPCHK(hipMemcpy(ctx->d_px, hx.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->d_py, hy.data(), Ps * sizeof(double), hipMemcpyHostToDevice));
-  }
   // batches: contiguous ranges of the sorted shard, pipelined on separate streams (one until the GSIP bound mode is
   // known, see set_batches)
   int rcb = set_batches(ctx, ctx->want_batches > 0 ? ctx->want_batches : 1);
@@ -980,22 +1036,33 @@ int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   return ctx->subs.empty() ? run_pipeline_leaf(ctx, N, coeffs, T) : run_pipeline_group(ctx, N, coeffs, T);
 }
 
+// Stage the host cloud on the device (one H2D of the AoS array) and plan + gather there.
+int upload_from_host(svsdf_ctx *ctx, const double *xyz, size_t P, int rk, int ws) {
+  HIPCHK(hipSetDevice(ctx->device));
+  double *d_xyz = nullptr;
+  if (P) {
+    HIPCHK(hipMalloc((void **)&d_xyz, 3 * P * sizeof(double)));
+    const hipError_t e = hipMemcpy(d_xyz, xyz, 3 * P * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_xyz); return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e, "upload of the query points failed"); }
+  }
+  const int rc = upload_shard_device(ctx, d_xyz, P, rk, ws);
+  if (d_xyz) (void)hipFree(d_xyz);
+  return rc;
+}
+
 int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
   if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
   if (P > 0xffffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points");
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<long long> order;
-  morton_order(xyz, P, ctx->cfg.flags, order);   // once, whatever the number of devices
   int rc = SVSDF_OK;
   if (ctx->subs.empty()) {
-    stripe_of(order, ctx->cfg.rank, ctx->cfg.world_size, ctx->shard_idx);
-    rc = upload_shard(ctx, xyz);
+    rc = upload_from_host(ctx, xyz, P, ctx->cfg.rank, ctx->cfg.world_size);
   } else {
+    // every device plans the whole cloud itself (a ~2 ms sort, in parallel on the devices' own host threads and
+    // PCIe links) and keeps its stripe
     const int G = (int)ctx->subs.size();
     rc = group_run(ctx, [&](int k) -> int {
-      svsdf_ctx *s = ctx->subs[k];
-      stripe_of(order, ctx->cfg.rank * G + k, ctx->cfg.world_size * G, s->shard_idx);
-      return upload_shard(s, xyz);
+      return upload_from_host(ctx->subs[k], xyz, P, ctx->cfg.rank * G + k, ctx->cfg.world_size * G);
     });
     ctx->P = 0;
     ctx->shard_idx.clear();
@@ -1217,6 +1284,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_env = true; }
+  if (const char *e = std::getenv("SVSDF_UB_RATIO")) { ctx->ub_threshold = std::atof(e); ctx->ub_thr_env = true; }
   if (const char *e = std::getenv("SVSDF_WIDE32")) ctx->wide32_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE8")) ctx->wide8_below = std::atoll(e);
@@ -1310,9 +1378,15 @@ int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P) {
 int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P) {
   if (!ctx || (!d_xyz_aos && P)) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_points_device: null argument");
   if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
-  // The Morton order and the stripes are planned on the host (the plan is shared by every device and rank):
-  // one D2H of the cloud, then the normal upload.  One-time setup per optimisation, never in the timed region.
-  HIPCHK(hipSetDevice(ctx->device));
+  if (P > 0xffffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points");
+  if (ctx->subs.empty()) {   // the cloud never leaves the device: keys, radix sort and stripe gather run there
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = upload_shard_device(ctx, d_xyz_aos, P, ctx->cfg.rank, ctx->cfg.world_size);
+    ctx->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+  }
+  // multi-device context: the other devices need the cloud too -- one D2H, then every device uploads and plans
+  HIPCHK(hipSetDevice(ctx->subs[0]->device));
   std::vector<double> h(3 * P);
   if (P) HIPCHK(hipMemcpy(h.data(), d_xyz_aos, 3 * P * sizeof(double), hipMemcpyDeviceToHost));
   return set_points_host(ctx, h.data(), P);

@@ -1295,4 +1295,84 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Query-point upload on the device (svsdf_set_points / svsdf_set_points_device): bounding box, Morton keys with the
+// input index in the low 32 bits, radix sort of the Morton half (host: hipcub), stripe gather into the SoA arrays.
+// The key formula is the host planner's (svsdf_shard_plan), operation for operation, so both give the same order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned part1by1_dev(unsigned x) {
+  x &= 0x0000ffffu;
+  x = (x ^ (x << 8)) & 0x00ff00ffu;
+  x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+  x = (x ^ (x << 2)) & 0x33333333u;
+  x = (x ^ (x << 1)) & 0x55555555u;
+  return x;
+}
+
+// per-block partial bounding boxes [xmin, xmax, ymin, ymax] + count of non-finite coordinates
+__global__ void __launch_bounds__(kBlock)
+k_points_bbox(const double *__restrict__ xyz, size_t P, double *__restrict__ part, int *__restrict__ nonfinite) {
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  double xmin = inf, xmax = -inf, ymin = inf, ymax = -inf;
+  int bad = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1];
+    if (!(fabs(x) < inf) || !(fabs(y) < inf)) ++bad;   // NaN or inf
+    if (x < xmin) xmin = x;
+    if (x > xmax) xmax = x;
+    if (y < ymin) ymin = y;
+    if (y > ymax) ymax = y;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    xmin = fmin(xmin, __shfl_xor(xmin, m, 64)); xmax = fmax(xmax, __shfl_xor(xmax, m, 64));
+    ymin = fmin(ymin, __shfl_xor(ymin, m, 64)); ymax = fmax(ymax, __shfl_xor(ymax, m, 64));
+    bad += __shfl_xor(bad, m, 64);
+  }
+  __shared__ double s[kBlock / 64][4];
+  __shared__ int sb[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) {
+    s[threadIdx.x >> 6][0] = xmin; s[threadIdx.x >> 6][1] = xmax; s[threadIdx.x >> 6][2] = ymin; s[threadIdx.x >> 6][3] = ymax;
+    sb[threadIdx.x >> 6] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) {
+      s[0][0] = fmin(s[0][0], s[w][0]); s[0][1] = fmax(s[0][1], s[w][1]);
+      s[0][2] = fmin(s[0][2], s[w][2]); s[0][3] = fmax(s[0][3], s[w][3]);
+      sb[0] += sb[w];
+    }
+    for (int q = 0; q < 4; ++q) part[4 * blockIdx.x + q] = s[0][q];
+    if (sb[0]) atomicAdd(nonfinite, sb[0]);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_points_keys(const double *__restrict__ xyz, size_t P, double xmin, double ymin, double ext, int keep_order,
+              unsigned long long *__restrict__ keys) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long code = 0ull;
+    if (!keep_order) {
+      const double fx = (xyz[3 * i] - xmin) / ext, fy = (xyz[3 * i + 1] - ymin) / ext;
+      const unsigned qx = (unsigned)fmin(65535.0, fmax(0.0, fx * 65535.0));
+      const unsigned qy = (unsigned)fmin(65535.0, fmax(0.0, fy * 65535.0));
+      code = (unsigned long long)(part1by1_dev(qx) | (part1by1_dev(qy) << 1));
+    }
+    keys[i] = (code << 32) | (unsigned long long)(i & 0xffffffffull);
+  }
+}
+
+// stripe rk of ws of the sorted order -> SoA coordinates + original indices
+__global__ void __launch_bounds__(kBlock)
+k_points_gather(const double *__restrict__ xyz, const unsigned long long *__restrict__ keys, size_t P, int rk, int ws,
+                size_t Ps, double *__restrict__ px, double *__restrict__ py, long long *__restrict__ idx_out) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < Ps; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = (size_t)rk + j * (size_t)ws;
+    const size_t i = (size_t)(keys[k] & 0xffffffffull);
+    px[j] = xyz[3 * i];
+    py[j] = xyz[3 * i + 1];
+    idx_out[j] = (long long)i;
+  }
+}
+
 }  // namespace svsdf
