@@ -115,6 +115,8 @@ struct svsdf_ctx {
   bool have_duration = false;
   bool host_only = false;  // SVSDF_FLAG_HOST_ONLY: MINCO / callback host logic only, no device
   int N = 0, K = 0;
+  int piece_time_mode = 0;     // this trajectory: 0 cumulative form (exactly equivalent here), 1 / 2 faithful chain
+  int stats_piece_time = 0;
 
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
@@ -445,11 +447,31 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
       if (std::isfinite(sl)) slack[c] = sl;
     }
   }
+  {
+    // Piece-local time: the reference subtracts the durations one after the other from t
+    // (TRJ:498-516); t - (T_0 + ... + T_{i-1}) in one subtraction is the same number only when every operation
+    // involved is exact.  That is guaranteed when all durations are coarse dyadic numbers (multiples of 2^-20 below
+    // 2^20, e.g. the 2.5 s of every BASELINE config): then all partial sums and all differences with any t < 2^30
+    // are exact in both forms.  Otherwise (an optimiser's durations are generic doubles) the faithful chain runs.
+    bool coarse = dur < 1073741824.0;
+    double tmin = std::numeric_limits<double>::infinity();
+    for (int i = 0; i < N; ++i) {
+      const double v = std::ldexp(T[i], 20);
+      coarse = coarse && T[i] < 1048576.0 && v == std::floor(v);
+      tmin = std::min(tmin, T[i]);
+    }
+    const int f = ctx->cfg.flags;
+    int mode = (f & SVSDF_FLAG_EXACT_PIECE_TIME) ? 1 : (f & SVSDF_FLAG_FAST_PIECE_TIME) ? 0 : (coarse ? 0 : 1);
+    if (mode == 1 && !(tmin >= 1e-6)) mode = 2;
+    ctx->piece_time_mode = mode;
+    ctx->stats_piece_time = mode;
+  }
   ctx->N = N;
   ctx->K = (int)K;
   HIPCHK(hipMemcpyAsync(ctx->d_in, ctx->h_in, need * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const size_t lds = (size_t)traj_lds_doubles(N) * sizeof(double);
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), lds, ctx->stream, ctx->d_in, N, dur, (int)K, ctx->d_traj,
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), lds, ctx->stream, ctx->d_in, N, dur, (int)K,
+                     ctx->piece_time_mode, ctx->d_traj,
                      ctx->d_pose, ctx->d_chunks, ctx->r_bound, ctx->d_ctl, ctx->nbatch);
   return SVSDF_OK;
 }
@@ -634,6 +656,7 @@ int set_batches(svsdf_ctx *ctx, int nb);   // below
 
 void fill_mode_stats(svsdf_ctx *ctx) {
   ctx->stats.gsip_bound_mode = ctx->ub_full ? 1 : 0;
+  ctx->stats.piece_time_exact = ctx->stats_piece_time;
   ctx->stats.bound_mode_decided = (ctx->ub_env || ctx->ub_tune > 0) ? 1 : 0;
   ctx->stats.bound_ratio = ctx->ub_ratio;
   ctx->stats.n_devices = 1;
@@ -985,6 +1008,7 @@ void merge_stats(svsdf_ctx *ctx) {
     t.solve_launches = std::max(t.solve_launches, a.solve_launches);
     t.gsip_iterations = std::max(t.gsip_iterations, a.gsip_iterations);
     t.gsip_bound_mode = std::max(t.gsip_bound_mode, a.gsip_bound_mode);
+    t.piece_time_exact = std::max(t.piece_time_exact, a.piece_time_exact);
     t.bound_ratio = std::max(t.bound_ratio, a.bound_ratio);
   }
   t.bound_mode_decided = 1;
@@ -1289,6 +1313,11 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE8")) ctx->wide8_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
+  if (const char *e = std::getenv("SVSDF_PIECE_TIME")) {   // exact | fast | auto (default)
+    ctx->cfg.flags &= ~(SVSDF_FLAG_EXACT_PIECE_TIME | SVSDF_FLAG_FAST_PIECE_TIME);
+    if (std::string(e) == "exact") ctx->cfg.flags |= SVSDF_FLAG_EXACT_PIECE_TIME;
+    else if (std::string(e) == "fast") ctx->cfg.flags |= SVSDF_FLAG_FAST_PIECE_TIME;
+  }
   for (int b = 0; b < kMaxBatches; ++b) {
     if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming) != hipSuccess)

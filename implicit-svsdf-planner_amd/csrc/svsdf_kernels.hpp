@@ -45,6 +45,8 @@ constexpr double kUnsolved = -1e300;               // sq_sdf marker: sample not 
 struct TrajDev {
   int N;
   int K;        // layer-1 samples (t = 0; t <= dur; t += 0.15, SWM:567)
+  int exact;    // piece-local time by the reference's successive subtractions: 0 no (cumulative form), 1 yes, 2 yes and
+                // without the comparison-free prefix (some piece shorter than 1e-6 s)
   double dur;   // SweptVolumeManager::traj_duration (SWM:376-385)
   double T[kMaxPieces];
   double S[kMaxPieces + 1];     // S[i] = T[0] + ... + T[i-1] (sequential sum)
@@ -76,6 +78,7 @@ struct BatchCtl {
 struct TrajL {
   const double *T, *S, *c;
   int N;
+  int exact;
   double dur;
 };
 
@@ -90,7 +93,7 @@ __device__ __forceinline__ TrajL stage_traj(const TrajDev *__restrict__ g, doubl
   for (int i = threadIdx.x; i < 18 * N; i += blockDim.x) c[i] = g->c[i];
   __syncthreads();
   TrajL tr;
-  tr.T = T; tr.S = S; tr.c = c; tr.N = N; tr.dur = g->dur;
+  tr.T = T; tr.S = S; tr.c = c; tr.N = N; tr.dur = g->dur; tr.exact = g->exact;
   return tr;
 }
 
@@ -99,6 +102,27 @@ __device__ __forceinline__ TrajL stage_traj(const TrajDev *__restrict__ g, doubl
 __device__ __forceinline__ int locate_piece(const TrajL &tr, double t, int i) {
   while (i < tr.N - 1 && t > tr.S[i + 1]) ++i;
   while (i > 0 && !(t > tr.S[i])) --i;
+  return i;
+}
+
+// Opt-in faithful form (SVSDF_FLAG_EXACT_PIECE_TIME): Trajectory::locatePieceIdx exactly as written (TRJ:498-516) --
+// the durations are subtracted one after the other from t (i roundings instead of one) and the piece index follows
+// from comparing the running remainder with T[i].  O(N) per call: +19 % (C2) ... +68 % (C3) evaluation time, which is
+// why the default locates on the cumulative start times (identical whenever the partial sums are exact, e.g. the
+// equal 2.5 s pieces of every BASELINE config; within i ulp(t) otherwise).
+__device__ __forceinline__ int locate_local_exact(const TrajL &tr, double t, double &s) {
+  int i = 0;
+  double dur = 0.0;
+  for (; i < tr.N && t > (dur = tr.T[i]); ++i) t -= dur;
+  if (i == tr.N) { --i; t += tr.T[i]; }
+  s = t;
+  return i;
+}
+// piece index and local time of global time t (either form)
+__device__ __forceinline__ int locate_local(const TrajL &tr, double t, int hint, double &s) {
+  if (tr.exact) return locate_local_exact(tr, t, s);
+  const int i = locate_piece(tr, t, hint);
+  s = t - tr.S[i];
   return i;
 }
 
@@ -208,6 +232,32 @@ struct PieceCache {
 __device__ __forceinline__ PieceCache piece_cache_init() { PieceCache pc; pc.piece = 0; pc.lo = 1.0; pc.hi = 0.0; return pc; }
 
 __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, PieceCache &pc) {
+  if (tr.exact) {   // wave-uniform
+    // Faithful piece-local time at the evaluation site.  The cached cumulative locate gives a candidate index ih
+    // (t in (S[ih], S[ih+1]]); the reference's chain r_0 = t, r_{j+1} = r_j - T_j runs without its comparisons for
+    // j < ih - 1 -- there r_j - T_j ~ t - S_{j+1} >= T_{ih-1} > 0 by a margin of >= min T (host: >= 1e-6, else
+    // exact == 2 and the full loop runs) against rounding of <= 64 ulp(t) -- and with them from there on, so index
+    // and local time are the reference's to the last bit (TRJ:498-516).
+    if (!(t > pc.lo && t <= pc.hi)) {
+      pc.piece = locate_piece(tr, t, pc.piece);
+      pc.lo = (pc.piece == 0) ? -1e300 : tr.S[pc.piece];
+      pc.hi = (pc.piece == tr.N - 1) ? 1e300 : tr.S[pc.piece + 1];
+    }
+    const int nb = (tr.exact == 2) ? 0 : pc.piece - 1;
+    double r = t;
+    int jj = 0;
+    for (; jj + 3 < nb; jj += 4) r = (((r - tr.T[jj]) - tr.T[jj + 1]) - tr.T[jj + 2]) - tr.T[jj + 3];
+    for (; jj < nb; ++jj) r -= tr.T[jj];
+    double dur_ = 0.0;
+    for (; jj < tr.N && r > (dur_ = tr.T[jj]); ++jj) r -= dur_;
+    if (jj == tr.N) { --jj; r += tr.T[jj]; }
+    double x_, y_, yaw_;
+    piece_pos(tr.c + jj * 18, r, x_, y_, yaw_);
+    Pose p_;
+    p_.x = x_; p_.y = y_;
+    sincos_exact(yaw_, &p_.sn, &p_.cs);
+    return p_;
+  }
   // same piece as locate_piece: t in (S[i], S[i+1]] (t <= S[1] for i = 0, t > S[N-1] for i = N-1)
   if (!(t > pc.lo && t <= pc.hi)) {
     pc.piece = locate_piece(tr, t, pc.piece);
@@ -225,8 +275,8 @@ __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, PieceCache &p
 }
 
 __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, int &piece) {
-  piece = locate_piece(tr, t, piece);
-  const double s = t - tr.S[piece];
+  double s;
+  piece = locate_local(tr, t, piece, s);
   double x, y, yaw;
   piece_pos(tr.c + piece * 18, s, x, y, yaw);
   Pose p;
@@ -263,7 +313,7 @@ __device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp,
 // k_prep: one block.  in = [coeffs (6N x 3 column-major) | T (N) | tk (K)] as uploaded.
 // Also clears the per-batch control blocks for this evaluation.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_prep(const double *__restrict__ in, int N, double dur, int K,
+__global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, int exact,
                        TrajDev *__restrict__ tr, Pose *__restrict__ pose,
                        Chunk *__restrict__ chunks, double r_bound, BatchCtl *__restrict__ ctl,
                        int nbatch) {
@@ -277,7 +327,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K,
     c.stat_solves = 0ull; c.stat_evals = 0ull; c.stat_scan = 0ull; c.stat_culled = 0ull;
   }
   if (threadIdx.x == 0) {
-    tr->N = N; tr->K = K; tr->dur = dur;
+    tr->N = N; tr->K = K; tr->dur = dur; tr->exact = exact;
     double s = 0.0;
     for (int i = 0; i < N; ++i) { tr->T[i] = T[i]; tr->S[i] = s; s += T[i]; }
     tr->S[N] = s;
@@ -813,20 +863,21 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
       continue;
     }
     // interior: velocity at t* with the low-speed rescans (SWM:929-954)
-    int piece = locate_piece(tr, ts, 0);
+    double sl;
+    int piece = locate_local(tr, ts, 0, sl);
     double vx, vy, w;
-    piece_vel(tr.c + piece * 18, ts - tr.S[piece], vx, vy, w);
+    piece_vel(tr.c + piece * 18, sl, vx, vy, w);
     if (sqrt(vx * vx + vy * vy + w * w) < 0.01) {
       if (ts < 0.1) {
         for (double t_scan = ts; t_scan <= tr.dur; t_scan += 0.1) {
-          piece = locate_piece(tr, t_scan, piece);
-          piece_vel(tr.c + piece * 18, t_scan - tr.S[piece], vx, vy, w);
+          piece = locate_local(tr, t_scan, piece, sl);
+          piece_vel(tr.c + piece * 18, sl, vx, vy, w);
           if (sqrt(vx * vx + vy * vy + w * w) >= 0.01) break;
         }
       } else if (ts > tr.dur - 0.1) {
         for (double t_scan = ts; t_scan >= 0; t_scan -= 0.1) {
-          piece = locate_piece(tr, t_scan, piece);
-          piece_vel(tr.c + piece * 18, t_scan - tr.S[piece], vx, vy, w);
+          piece = locate_local(tr, t_scan, piece, sl);
+          piece_vel(tr.c + piece * 18, sl, vx, vy, w);
           if (sqrt(vx * vx + vy * vy + w * w) >= 0.01) break;
         }
       }
@@ -1189,9 +1240,9 @@ k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
       double sdf_cost = -1.0, sdf_out_grad = 0.0;
       smoothed_l1(safety_hor - sdf_value, 0.01, sdf_cost, sdf_out_grad);
       if (sdf_cost > 0) {
-        i = locate_piece(tr, time_star, 0);
+        double s1;
+        i = locate_local(tr, time_star, 0, s1);
         const double *c = tr.c + i * 18;
-        const double s1 = time_star - tr.S[i];
         const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
         const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
         const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};

@@ -61,7 +61,7 @@ class Stats(C.Structure):
                 ("solve_launches", C.c_uint), ("gsip_iterations", C.c_uint), ("culled_points", C.c_ulonglong),
                 ("gsip_bound_mode", C.c_int), ("bound_mode_decided", C.c_int), ("bound_ratio", C.c_double),
                 ("n_devices", C.c_int), ("combine", C.c_int), ("combine_ms", C.c_double), ("setup_ms", C.c_double),
-                ("solve_ms_sum", C.c_double)]
+                ("piece_time_exact", C.c_int), ("solve_ms_sum", C.c_double)]
 
 
 class SvsdfError(RuntimeError):
@@ -241,6 +241,8 @@ class OccupancyMap:
 
 FLAG_KEEP_INPUT_ORDER = 1
 FLAG_HOST_ONLY = 2
+FLAG_EXACT_PIECE_TIME = 4
+FLAG_FAST_PIECE_TIME = 8
 COMBINE_AUTO, COMBINE_HOST, COMBINE_RCCL = 0, 1, 2
 
 

@@ -104,6 +104,16 @@ typedef struct svsdf_config {
                                          (svsdf_lmbm_prepare / svsdf_lmbm_finish, MINCO helpers);
                                          every device entry point fails with SVSDF_ERR_NO_DEVICE */
 
+/* Piece-local time.  The reference subtracts the piece durations one after the other from t
+ * (Trajectory::locatePieceIdx, trajectory.hpp:498-516).  Default (neither flag): the library does the same whenever
+ * that can differ from t - (T_0+...+T_{i-1}) in a single subtraction, i.e. unless every duration is a coarse dyadic
+ * number (multiple of 2^-20, like the 2.5 s of the BASELINE configs), in which case both forms are exact and equal and
+ * the cheaper one runs.  svsdf_stats.piece_time_exact tells which form the last evaluation used. */
+#define SVSDF_FLAG_EXACT_PIECE_TIME 4  /* always the reference's chain (O(piece index) per SDF evaluation) */
+#define SVSDF_FLAG_FAST_PIECE_TIME 8   /* always the single subtraction: <= i ulp(t) away from the reference for generic
+                                         durations, which flat stretches of SDF(t) amplify (differential fuzzing: gradient
+                                         up to 5e-5 relative off, vs 1e-5 with the chain); round 1's behaviour */
+
 typedef struct svsdf_ctx svsdf_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -297,6 +307,8 @@ typedef struct svsdf_stats {
   int combine;                        /* SVSDF_COMBINE_* used by the last evaluation */
   double combine_ms;                  /* host wall time from "all devices done" to "summed partial on the host" */
   double setup_ms;                    /* host wall time of the last svsdf_set_points (sort + upload) */
+  int piece_time_exact;               /* 0: single-subtraction piece-local time (exactly equivalent for this trajectory's
+                                         durations, or forced by SVSDF_FLAG_FAST_PIECE_TIME); 1, 2: the reference's chain */
   double solve_ms_sum;                /* plain sum of the k_solve launch durations (solve_ms merges the intervals of
                                          launches that ran concurrently on different streams) (profiling on) */
 } svsdf_stats;

@@ -568,6 +568,11 @@ static inline void trig_sincos(const orc_ctx *ctx, double a, double *sn, double 
 static inline double trig_atan2(const orc_ctx *ctx, double y, double x) {
   return ctx->trig_mode ? dev_atan2(y, x) : atan2(y, x);
 }
+void orc_set_modes(orc_ctx *ctx, int trig_mode, int cum_locate) {
+  /* the two diagnostic switches separately: device-library trig (1) and cumulative piece location (1) */
+  ctx->trig_mode = trig_mode ? 1 : 0;
+  ctx->traj.cum_locate = cum_locate ? 1 : 0;
+}
 void orc_set_trig_mode(orc_ctx *ctx, int mode) {
   ctx->trig_mode = mode ? 1 : 0;
   ctx->traj.cum_locate = ctx->trig_mode;

@@ -139,6 +139,7 @@ void orc_get_counters(const orc_ctx *ctx, orc_counters *out);
  * subtractions (see svsdf_oracle.c) -- the two places where the HIP kernels' arithmetic is not the reference's
  * operation for operation.  Mode 0 (default) is the oracle of record. */
 void orc_set_trig_mode(orc_ctx *ctx, int mode);
+void orc_set_modes(orc_ctx *ctx, int trig_mode, int cum_locate);
 
 /* ---- MINCO S3NU + full callback (a14) --------------------------------------- */
 /* x = [tau_0..tau_{N-1}, q_0 (x,y,yaw), ..., q_{N-2}], n = N + 3(N-1). Returns cost,

@@ -44,13 +44,17 @@ for case in range(ncase):
         pts[:5, :2] = anchors[rng.integers(0, len(anchors), 5)]                # points exactly on waypoints (zero level set of some shapes)
     sh = float(rng.uniform(0.2, 1.5))
     kw = dict(safety_hor=sh, weight_p=60.0, rho=3.8, poly_params=pp, polygon=poly, head_state=hs, tail_state=ts)
-    ctx = svsdf_amd.SvsdfContext(shape=shape, device=0, **kw)
+    # FUZZ_PIECE_TIME=fast: the single-subtraction piece-local time (round 1's arithmetic); default: the library's own
+    # choice, i.e. the reference's chain for these generic durations
+    fast_time = os.environ.get("FUZZ_PIECE_TIME", "auto") == "fast"
+    exact_time = not fast_time
+    ctx = svsdf_amd.SvsdfContext(shape=shape, device=0, flags=svsdf_amd.FLAG_FAST_PIECE_TIME if fast_time else 0, **kw)
     ctx.set_points(pts)
     o = orc.Oracle(shape, **kw)
     o.set_traj(coeffs, T)
     devtrig = os.environ.get("FUZZ_DEVICE_TRIG", "0") == "1"   # oracle in device-arithmetic mode (orc_set_trig_mode)
     if devtrig:
-        o.set_trig_mode(1)
+        o.set_modes(1, 0 if exact_time else 1)   # device trig; piece time as the HIP path computes it
     try:
         cost, gT, gC = ctx.eval_penalty(coeffs, T)
         sdf, tstar, g, _ = ctx.query_points(coeffs, T)
