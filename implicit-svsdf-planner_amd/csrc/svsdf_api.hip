@@ -124,7 +124,8 @@ struct svsdf_ctx {
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
-  bool ub_env = false;         // env SVSDF_UB_FULL=0/1 pins the mode, otherwise run_pipeline decides after one evaluation
+  bool ub_lazy = false;        // with ub_full: only the samples in the cheap-bound band are scanned (k_round MODE 2)
+  bool ub_env = false;         // env SVSDF_UB_FULL=0/1/2 pins the mode, otherwise run_pipeline decides after one evaluation
   int ub_tune = 0;             // evaluations since the point set changed that took part in the decision (0 or 1)
   double ub_ratio = 0.0;       // GSIP solves / GSIP samples of the deciding (cheap-bound) evaluation
   double ub_threshold = 0.5;   // env SVSDF_UB_RATIO (analytic shapes; Polygon 0.2)
@@ -308,8 +309,9 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
 #undef CALL
 }
 
-template <bool FULLUB>
+template <int UBMODE>
 void launch_round_m(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
+  constexpr bool FULLUB = UBMODE != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
   const size_t lds = table_lds_doubles(ctx) * sizeof(double);
   // late iterations hold few points and are latency-bound: request every sample there, which
@@ -319,21 +321,22 @@ void launch_round_m(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const double sel = (FULLUB && !ctx->select_env) ? 0.01 : ctx->select_delta;
   const int all_it = (FULLUB && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
   const double delta = (it >= all_it) ? 1e300 : sel;
+  const double band_delta = (it >= all_it) ? 1e300 : ctx->select_delta;   // lazy mode: cheap-bound band that gets scanned
   // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per
   // point; later rounds have 18-21 samples: 32 lanes per point (either handles any count)
   if (it < ctx->round_lp8_iters) {
     const unsigned grid = (unsigned)std::min<long long>((pts * 8 + kRoundBlock - 1) / kRoundBlock, 1024);
 #define CALL(S)                                                                                           \
-  hipLaunchKernelGGL((k_round<S, 8, FULLUB>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,   \
-                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, \
+  hipLaunchKernelGGL((k_round<S, 8, UBMODE>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,   \
+                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, band_delta, \
                      ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
     SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
   } else {
     const unsigned grid = (unsigned)std::min<long long>((pts * 32 + kRoundBlock - 1) / kRoundBlock, 1024);
 #define CALL(S)                                                                                           \
-  hipLaunchKernelGGL((k_round<S, 32, FULLUB>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,  \
-                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, \
+  hipLaunchKernelGGL((k_round<S, 32, UBMODE>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,  \
+                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, band_delta, \
                      ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
     SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
 #undef CALL
@@ -341,8 +344,9 @@ void launch_round_m(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
 }
 
 void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
-  if (ctx->ub_full) launch_round_m<true>(ctx, st, b, it);
-  else launch_round_m<false>(ctx, st, b, it);
+  if (ctx->ub_full && ctx->ub_lazy) launch_round_m<2>(ctx, st, b, it);
+  else if (ctx->ub_full) launch_round_m<1>(ctx, st, b, it);
+  else launch_round_m<0>(ctx, st, b, it);
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
@@ -655,7 +659,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
 int set_batches(svsdf_ctx *ctx, int nb);   // below
 
 void fill_mode_stats(svsdf_ctx *ctx) {
-  ctx->stats.gsip_bound_mode = ctx->ub_full ? 1 : 0;
+  ctx->stats.gsip_bound_mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
   ctx->stats.piece_time_exact = ctx->stats_piece_time;
   ctx->stats.bound_mode_decided = (ctx->ub_env || ctx->ub_tune > 0) ? 1 : 0;
   ctx->stats.bound_ratio = ctx->ub_ratio;
@@ -702,7 +706,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   // evaluations per mode with the wall clock; the rule reproduces its choices on C1-C5 without the five extra
   // evaluations and without depending on the box.)
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
-  if (deciding) ctx->ub_full = false;
+  if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; }
   int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/true);
   if (rc) return rc;
   rc = finish(ctx, true);
@@ -713,10 +717,14 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     // Polygon: an SDF evaluation costs ~10 x an analytic shape's (one pass over the outline per evaluation), a table
     // scan proportionally less of a solve, so scanning pays from a lower ratio (C5, 1 M points: 55.5 -> 48.3 ms)
     const double thr = ctx->ub_thr_env ? ctx->ub_threshold : (ctx->cfg.shape_id == SVSDF_SHAPE_Polygon ? 0.2 : ctx->ub_threshold);
-    ctx->ub_full = ctx->ub_ratio > thr;
+    // below the threshold a large shard still gains from scanning -- but only the samples the cheap bound would have
+    // had solved (lazy mode: NS, star / 16 pieces / 1 M points, 12.3 -> 11.4 ms; at 100 k points no gain)
+    const bool large = ctx->P >= 400000;
+    ctx->ub_full = ctx->ub_ratio > thr || large;
+    ctx->ub_lazy = !(ctx->ub_ratio > thr);
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
-    if (ctx->ub_full && ctx->want_batches == 0 && ctx->P >= 400000) rc = set_batches(ctx, 4);
+    if (ctx->ub_full && ctx->want_batches == 0 && large) rc = set_batches(ctx, ctx->ub_lazy ? 2 : 4);
   }
   fill_mode_stats(ctx);
   ctx->h_partial = ctx->h_out;
@@ -921,7 +929,7 @@ int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, i
   ctx->have_prev_nsolve = false;
   ctx->ub_tune = 0;
   ctx->ub_ratio = 0.0;
-  if (!ctx->ub_env) ctx->ub_full = false;
+  if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; }
   if (!ctx->G_env) {
     ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
@@ -1307,7 +1315,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
-  if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_env = true; }
+  if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_lazy = std::atoi(e) == 2; ctx->ub_env = true; }
   if (const char *e = std::getenv("SVSDF_UB_RATIO")) { ctx->ub_threshold = std::atof(e); ctx->ub_thr_env = true; }
   if (const char *e = std::getenv("SVSDF_WIDE32")) ctx->wide32_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);

@@ -655,7 +655,8 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     if (qs.seed_k) {
       best_k = qs.seed_k[slot];
       best_d = qs.seed_d[slot];
-    } else {
+    }
+    if (!qs.seed_k || best_k < 0) {   // no seed for this query (main points, cheap-bound samples, unscanned lazy samples)
       scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan);
     }
     if (culled) {
@@ -819,6 +820,9 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 // GSIP state (getTrueSDFofSweptVolume SWM:916-1018), one entry per interior point; every array
 // is indexed by (batch start + interior index within the batch).
 // ---------------------------------------------------------------------------------------------
+#ifndef SVSDF_LAZY_REPS
+#define SVSDF_LAZY_REPS 2   // scan passes of the lazy bound mode: the band, then its extension (a third changes nothing)
+#endif
 enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
 struct GsipState {
   int *pt;          // index of the (sorted) main point
@@ -921,14 +925,17 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
 #define SVSDF_ROUND_BLOCK 1024
 #endif
 constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
-template <int SHAPE, int LP, bool FULL>
+// MODE: 0 cheap bound (nearest chunk), 1 full (every new sample scanned), 2 lazy (cheap bound for all, the sample's own
+// table scan only for those within `band_delta` of the best cheap bound -- the ones the cheap mode would solve)
+template <int SHAPE, int LP, int MODE>
 __global__ void __launch_bounds__(kRoundBlock)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
-        const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta,
+        const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta, double band_delta,
         double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx,
         double *__restrict__ res_gy, BatchCtl *__restrict__ ctl) {
   static_assert(LP == 8 || LP == 32, "lanes per point");
+  constexpr bool FULL = MODE == 1;
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   extern __shared__ double round_lds[];
   __shared__ int s_cnt[3][kRoundBlock / LP];   // per point slot: solves, next-list entries, samples
@@ -1065,7 +1072,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
             const double qx = cx + 1.0 * r * cos(theta);
             const double qy = cy + 1.0 * r * sin(theta);
             sqx_l[ps] = qx; sqy_l[ps] = qy;
-            if constexpr (!FULL) {
+            if constexpr (MODE != 1) {
               // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
               double d2min = 1e300;
               int c0 = 0;
@@ -1125,6 +1132,97 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
               gs.sq_k[s] = kk[ps];
             }
         }
+        if constexpr (MODE == 2) {
+          // Lazy scans: the cheap bounds single out the samples the cheap mode would solve (within band_delta of the
+          // best one); those get their own pruned table scan (8 lanes per sample, LP / 8 at a time) and only the best
+          // of THEM by the scanned bound are requested; the seeds go to k_solve (sq_k >= 0), unscanned samples keep
+          // their cheap bound (sq_k = -1: a supplementary solve scans itself).  Any selection is exact: closing the
+          // round requests whatever unsolved sample's bound still reaches the best solved value.
+          constexpr int SG = LP / 8;
+          const int sg = l >> 3;
+          double uc = -1e300;
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) uc = fmax(uc, ub[ps]);
+          uc = fmax(uc, Grp<LP>::template xchg<0>(uc));
+          uc = fmax(uc, Grp<LP>::template xchg<1>(uc));
+          uc = fmax(uc, Grp<LP>::template xchg<2>(uc));
+          if constexpr (LP == 32) {
+            uc = fmax(uc, Grp<LP>::template xchg<3>(uc));
+            uc = fmax(uc, Grp<LP>::template xchg<4>(uc));
+          }
+          bool inband[NP], scanned[NP];
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) { inband[ps] = valid[ps] && ub[ps] >= uc - band_delta; scanned[ps] = false; kk[ps] = -1; }
+          double u2 = -1e300;   // best scanned bound so far
+          for (int rep = 0; rep < SVSDF_LAZY_REPS; ++rep) {
+            unsigned mp[NP];
+            int myrank[NP];
+            int nb = 0;
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              mp[ps] = ballot_g(inband[ps] && !scanned[ps]);
+              myrank[ps] = nb + __popc(mp[ps] & lt_mask);
+              nb += __popc(mp[ps]);
+            }
+            if (nb == 0) break;
+            for (int p = 0; p * SG < nb; ++p) {
+              const int r = p * SG + sg;          // rank (among the pending samples) this 8-lane sub-group scans
+              int rr = r, sps = 0, sl = 0;
+              bool found = false;
+#pragma unroll
+              for (int ps = 0; ps < NP; ++ps) {
+                const int c = __popc(mp[ps]);
+                if (!found && r < nb && rr < c) {
+                  unsigned m = mp[ps];
+                  for (int q = 0; q < rr; ++q) m &= m - 1u;
+                  sl = __ffs(m) - 1;
+                  sps = ps;
+                  found = true;
+                } else if (!found) {
+                  rr -= c;
+                }
+              }
+              double sxs = sqx_l[0], sys = sqy_l[0];
+#pragma unroll
+              for (int ps = 1; ps < NP; ++ps)
+                if (sps == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
+              const double qx = __shfl(sxs, sl, LP), qy = __shfl(sys, sl, LP);
+              double bd = -1e300;
+              int bk = 0;
+              if (found) {
+                bool cu;
+                scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
+              }
+#pragma unroll
+              for (int ps = 0; ps < NP; ++ps) {
+                const bool mine = inband[ps] && !scanned[ps] && (myrank[ps] / SG == p);
+                const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
+                const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
+                if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
+              }
+            }
+            // extend the band to unscanned samples whose cheap bound still reaches the best scanned one
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) u2 = scanned[ps] ? fmax(u2, ub[ps]) : u2;
+            u2 = fmax(u2, Grp<LP>::template xchg<0>(u2));
+            u2 = fmax(u2, Grp<LP>::template xchg<1>(u2));
+            u2 = fmax(u2, Grp<LP>::template xchg<2>(u2));
+            if constexpr (LP == 32) {
+              u2 = fmax(u2, Grp<LP>::template xchg<3>(u2));
+              u2 = fmax(u2, Grp<LP>::template xchg<4>(u2));
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) inband[ps] = inband[ps] || (valid[ps] && !scanned[ps] && ub[ps] >= u2 - delta);
+          }
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps)
+            if (valid[ps]) {
+              const size_t s = (size_t)(l + LP * ps) * stride + ia;
+              gs.sq_ub[s] = ub[ps];
+              gs.sq_k[s] = kk[ps];
+              if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
+            }
+        }
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) umax = fmax(umax, ub[ps]);
         umax = fmax(umax, Grp<LP>::template xchg<0>(umax));
@@ -1174,7 +1272,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     if (push_next && l == 0) nxt[s_base[1][hw]] = a;
     __syncthreads();
   }
-  if constexpr (FULL) {
+  if constexpr (MODE != 0) {
     unsigned long long tc = n_scan;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tc += __shfl_xor(tc, m, 64);

@@ -300,7 +300,8 @@ typedef struct svsdf_stats {
   unsigned int solve_launches;        /* k_solve launches of the last evaluation */
   unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
   unsigned long long culled_points;   /* main queries proven inactive (sdf > safety_hor) without a solve */
-  int gsip_bound_mode;                /* 0 = cheap chunk bound, 1 = full table scan per GSIP sample */
+  int gsip_bound_mode;                /* 0 = cheap chunk bound, 1 = table scan of every GSIP sample, 2 = lazy: table scan of
+                                         the samples within the selection band of the cheap bound only */
   int bound_mode_decided;             /* 1 once the mode is fixed for this point set (after <= 1 evaluation) */
   double bound_ratio;                 /* GSIP solves / samples of the deciding evaluation (rule: > 0.5 -> full) */
   int n_devices;                      /* devices that took part (1 unless svsdf_config::n_devices > 1) */

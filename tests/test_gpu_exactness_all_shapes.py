@@ -85,6 +85,7 @@ def test_prune_cull_bound_mode_and_width_are_exact(built, shape, dist):
     for env in (dict(SVSDF_PRUNE=1, SVSDF_CULL=0, SVSDF_UB_FULL=0, SVSDF_G=4),
                 dict(SVSDF_PRUNE=1, SVSDF_CULL=1, SVSDF_UB_FULL=0, SVSDF_G=8),
                 dict(SVSDF_PRUNE=1, SVSDF_CULL=1, SVSDF_UB_FULL=1, SVSDF_G=16),
+                dict(SVSDF_PRUNE=1, SVSDF_CULL=1, SVSDF_UB_FULL=2, SVSDF_G=2),
                 dict()):                                                     # the library's own choices
         got = _run(w, env)
         _same(got, ref, (shape, dist, env))

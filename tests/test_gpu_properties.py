@@ -183,6 +183,12 @@ def test_gsip_bound_modes_are_invisible(built):
             return out, st, q
         (c0, gT0, gC0), st0, q0 = _with_env(dict(SVSDF_UB_FULL=0), run)
         (c1, gT1, gC1), st1, q1 = _with_env(dict(SVSDF_UB_FULL=1), run)
+        (c2, gT2, gC2), st2, q2 = _with_env(dict(SVSDF_UB_FULL=2), run)     # lazy: scans only the cheap bound's band
+        for a, b in zip(q0[:3], q2[:3]):
+            np.testing.assert_array_equal(a, b)
+        assert c2 == c0
+        np.testing.assert_array_equal(gC2, gC0)
+        assert st2["solves"] <= st0["solves"] and st2["gsip_bound_mode"] == 2
         for a, b in zip(q0[:3], q1[:3]):
             np.testing.assert_array_equal(a, b)          # sdf, t*, gradient direction: bit for bit
         assert c1 == c0
