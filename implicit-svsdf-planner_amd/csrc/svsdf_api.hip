@@ -27,8 +27,8 @@
 #include <vector>
 
 #include "../../include/svsdf_c.h"
-#include "svsdf_kernels.hpp"
-#include "svsdf_frontend.hpp"
+#define SVSDF_API_TU   // this translation unit compiles the shape-independent kernels of svsdf_kernels.hpp
+#include "svsdf_launch.hpp"
 #include "svsdf_lbfgs.hpp"
 #include "svsdf_minco.hpp"
 #include "svsdf_points.hpp"
@@ -234,27 +234,53 @@ size_t next_event(svsdf_ctx *ctx) {
   return ctx->ev_used++;
 }
 
-// ---- kernel dispatch over the shape id ---------------------------------------------------------
-#ifdef SVSDF_FAST_BUILD  // development builds: star / sdHorseshoe / sdHeart / Polygon only
-#define SVSDF_FOR_SHAPE(id, CALL)                       \
-  switch (id) {                                         \
-    case 4: CALL(4); break;   case 6: CALL(6); break;   \
-    case 7: CALL(7); break;   default: CALL(16); break; \
+// ---- kernel dispatch over the shape id: the shape-templated kernels live in four translation units
+// (svsdf_shape_slice.hip, shapes with id % 4 == slice); a development build (-DSVSDF_FAST_BUILD) holds only star /
+// sdHorseshoe / sdHeart / Polygon and serves every other id with the Polygon kernels
+#define SVSDF_SLICE_DISPATCH(NAME, ...)                      \
+  switch (shape % kNSlices) {                                \
+    case 0: return NAME##_s0(shape, __VA_ARGS__);            \
+    case 1: return NAME##_s1(shape, __VA_ARGS__);            \
+    case 2: return NAME##_s2(shape, __VA_ARGS__);            \
+    default: return NAME##_s3(shape, __VA_ARGS__);           \
   }
+int compiled_shape(int shape) {
+#ifdef SVSDF_FAST_BUILD
+  return (shape == 4 || shape == 6 || shape == 7) ? shape : 16;
 #else
-#define SVSDF_FOR_SHAPE(id, CALL)                       \
-  switch (id) {                                         \
-    case 0: CALL(0); break;   case 1: CALL(1); break;   \
-    case 2: CALL(2); break;   case 3: CALL(3); break;   \
-    case 4: CALL(4); break;   case 5: CALL(5); break;   \
-    case 6: CALL(6); break;   case 7: CALL(7); break;   \
-    case 8: CALL(8); break;   case 9: CALL(9); break;   \
-    case 10: CALL(10); break; case 11: CALL(11); break; \
-    case 12: CALL(12); break; case 13: CALL(13); break; \
-    case 14: CALL(14); break; case 15: CALL(15); break; \
-    default: CALL(16); break;                           \
-  }
+  return shape;
 #endif
+}
+}  // namespace
+namespace svsdf {
+bool launch_k_solve(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_solve, G, grid, block, lds, st, a)
+}
+bool launch_k_round(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_round, lp, mode, grid, lds, st, a)
+}
+bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_classify, grid, lds, st, a)
+}
+bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_rbound, grid, st, sp, rmax, nrad, nang, out)
+}
+bool launch_k_subsw(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,
+                    const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_subsw, grid, st, sp, father, child, offs, pts, kt, nkt, flag)
+}
+bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu,
+                            int size_side, double safemargin, const double *yaw, unsigned char *map) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_shape_kernels, grid, st, sp, ks, count, resu, size_side, safemargin, yaw, map)
+}
+}  // namespace svsdf
+namespace {
 
 // Persistent-grid launcher of the argmin kernel.  max_queries bounds the (possibly device-side)
 // query count and sizes the grid; surplus blocks exit before touching LDS.
@@ -262,9 +288,9 @@ size_t table_lds_doubles(const svsdf_ctx *ctx) {
   return 4 * (size_t)ctx->K + 4 * (size_t)((ctx->K + kChunk - 1) / kChunk);
 }
 
-template <int S, int G, int U>
-void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long long max_queries, double *out_sdf,
-                     double *out_t, BatchCtl *ctl, int work_idx, double cull_thresh) {
+void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long max_queries, double *out_sdf,
+                  double *out_t, BatchCtl *ctl, int work_idx,
+                  double cull_thresh = std::numeric_limits<double>::infinity()) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
   const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N)) * sizeof(double);
@@ -276,8 +302,8 @@ void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long lo
   const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  hipLaunchKernelGGL((k_solve<S, G, U>), dim3(grid), dim3(blk), lds, st, ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks,
-                     ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh);
+  const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh};
+  (void)launch_k_solve(ctx->cfg.shape_id, G, grid, (unsigned)blk, lds, st, a);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -286,78 +312,34 @@ void launch_solve_sg(svsdf_ctx *ctx, hipStream_t st, const QuerySet &qs, long lo
   ctx->stats.solve_launches++;
 }
 
-template <int S>
-void launch_solve_s(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, double *out_sdf,
-                    double *out_t, BatchCtl *ctl, int work_idx, double cull_thresh) {
-  // G lanes per query (G candidates / samples per step); the U = 2 interleaving (two evaluations per lane) was
-  // measured and dropped, only U = 1 is instantiated
-  switch (G) {
-    case 1: launch_solve_sg<S, 1, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
-    case 2: launch_solve_sg<S, 2, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
-    case 8: launch_solve_sg<S, 8, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
-    case 16: launch_solve_sg<S, 16, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
-    case 32: launch_solve_sg<S, 32, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
-    default: launch_solve_sg<S, 4, 1>(ctx, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh); break;
-  }
-}
-
-void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, long long mq, double *out_sdf,
-                  double *out_t, BatchCtl *ctl, int work_idx,
-                  double cull_thresh = std::numeric_limits<double>::infinity()) {
-#define CALL(S) launch_solve_s<S>(ctx, G, st, qs, mq, out_sdf, out_t, ctl, work_idx, cull_thresh)
-  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
-}
-
-template <int UBMODE>
-void launch_round_m(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
-  constexpr bool FULLUB = UBMODE != 0;
+void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
+  const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;   // k_round MODE: cheap / full / lazy bound
+  const bool scans = mode != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
   const size_t lds = table_lds_doubles(ctx) * sizeof(double);
   // late iterations hold few points and are latency-bound: request every sample there, which
   // avoids supplementary iterations at no cost in time
-  // the seed bound of the full-scan mode is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
+  // the seed bound of the scanning modes is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
   // iteration 7); the chunk bound of the cheap mode needs 0.1 m / iteration 5.  Env values override both.
-  const double sel = (FULLUB && !ctx->select_env) ? 0.01 : ctx->select_delta;
-  const int all_it = (FULLUB && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
+  const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
+  const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
   const double delta = (it >= all_it) ? 1e300 : sel;
   const double band_delta = (it >= all_it) ? 1e300 : ctx->select_delta;   // lazy mode: cheap-bound band that gets scanned
   // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per
   // point; later rounds have 18-21 samples: 32 lanes per point (either handles any count)
-  if (it < ctx->round_lp8_iters) {
-    const unsigned grid = (unsigned)std::min<long long>((pts * 8 + kRoundBlock - 1) / kRoundBlock, 1024);
-#define CALL(S)                                                                                           \
-  hipLaunchKernelGGL((k_round<S, 8, UBMODE>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,   \
-                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, band_delta, \
-                     ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
-    SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
-  } else {
-    const unsigned grid = (unsigned)std::min<long long>((pts * 32 + kRoundBlock - 1) / kRoundBlock, 1024);
-#define CALL(S)                                                                                           \
-  hipLaunchKernelGGL((k_round<S, 32, UBMODE>), dim3(grid), dim3(kRoundBlock), lds, st, ctx->d_traj, ctx->d_pose,  \
-                     ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta, band_delta, \
-                     ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b)
-    SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
-  }
-}
-
-void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
-  if (ctx->ub_full && ctx->ub_lazy) launch_round_m<2>(ctx, st, b, it);
-  else if (ctx->ub_full) launch_round_m<1>(ctx, st, b, it);
-  else launch_round_m<0>(ctx, st, b, it);
+  const int lp = (it < ctx->round_lp8_iters) ? 8 : 32;
+  const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, 1024);
+  const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta,
+                      band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
+  (void)launch_k_round(ctx->cfg.shape_id, lp, mode, grid, lds, st, a);
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
   const unsigned grid = (unsigned)std::min<long long>(((long long)ctx->bcount[b] + kBlock - 1) / kBlock, 2048);
   const size_t lds = (size_t)traj_lds_doubles(ctx->N) * sizeof(double);
-#define CALL(S)                                                                                      \
-  hipLaunchKernelGGL((k_classify<S>), dim3(grid), dim3(kBlock), lds, st, ctx->d_traj, ctx->sp,       \
-                     ctx->d_px, ctx->d_py, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,       \
-                     ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->d_ctl + b)
-  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
+  const ClassifyLaunch a{ctx->d_traj, ctx->sp, ctx->d_px, ctx->d_py, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,
+                         ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->d_ctl + b};
+  (void)launch_k_classify(ctx->cfg.shape_id, grid, lds, st, a);
 }
 
 // Upload (coeffs, T), update traj_duration like SweptVolumeManager::updateTraj (SWM:376-385),
@@ -1353,9 +1335,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     if (hipMemset(ctx->d_out, 0, sizeof(double)) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;
     const unsigned grid = (unsigned)((nrad * nang + kBlock - 1) / kBlock);
-#define CALL(S) hipLaunchKernelGGL((k_rbound<S>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sp, 60.0, nrad, nang, ctx->d_out)
-    SVSDF_FOR_SHAPE(cfg->shape_id, CALL)
-#undef CALL
+    (void)launch_k_rbound(cfg->shape_id, grid, ctx->stream, ctx->sp, 60.0, nrad, nang, ctx->d_out);
     double rb = 0.0;
     if (hipMemcpyAsync(&rb, ctx->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -1623,11 +1603,7 @@ int svsdf_check_sub_sw_collision(svsdf_ctx *ctx, size_t n_edges, const double *f
   HIPCHK(hipMemcpyAsync(ctx->d_fe, h, need * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(ctx->d_fe_flag, 0, n_edges * sizeof(int), st));   // hit flags: 1 = some sdf < 0
   const dim3 grid((unsigned)n_edges, (unsigned)((max_pts + kSubswPoints - 1) / kSubswPoints));
-#define CALL(S)                                                                                         \
-  hipLaunchKernelGGL((k_subsw<S>), grid, dim3(kSubswBlock), 0, st, ctx->sp, d_father, d_child, d_offs,  \
-                     d_pts, d_kt, nkt, ctx->d_fe_flag)
-  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
+  (void)launch_k_subsw(ctx->cfg.shape_id, grid, st, ctx->sp, d_father, d_child, d_offs, d_pts, d_kt, nkt, ctx->d_fe_flag);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_fe_flag.data(), ctx->d_fe_flag, n_edges * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1672,11 +1648,8 @@ int svsdf_shape_kernels(svsdf_ctx *ctx, int kernel_size, int kernel_count, doubl
   hipStream_t st = ctx->stream;
   hipError_t e1 = hipMemcpyAsync(d_yaw, yaws.data(), count * sizeof(double), hipMemcpyHostToDevice, st);
   const unsigned grid = (unsigned)((cells * count + kBlock - 1) / kBlock);
-#define CALL(S)                                                                                             \
-  hipLaunchKernelGGL((k_shape_kernels<S>), dim3(grid), dim3(kBlock), 0, st, ctx->sp, kernel_size, count,    \
-                     kernel_resolution, size_side, safemargin, d_yaw, d_map)
-  SVSDF_FOR_SHAPE(ctx->cfg.shape_id, CALL)
-#undef CALL
+  (void)launch_k_shape_kernels(ctx->cfg.shape_id, grid, st, ctx->sp, kernel_size, count, kernel_resolution, size_side,
+                               safemargin, d_yaw, d_map);
   hipError_t e2 = hipGetLastError();
   hipError_t e3 = hipMemcpyAsync(map_out, d_map, cells * count, hipMemcpyDeviceToHost, st);
   hipError_t e4 = hipStreamSynchronize(st);

@@ -211,6 +211,7 @@ __device__ __forceinline__ void sincos_exact(double a, double *sn, double *cs) {
   *cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
 }
 
+#ifdef SVSDF_API_TU   // shape-independent kernel: compiled once, by svsdf_api.hip
 // mismatch counter for sincos_exact vs the library sincos (diagnostics / test only)
 __global__ void k_sincos_check(double lo, double hi, int n, unsigned long long *mism) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,6 +223,8 @@ __global__ void k_sincos_check(double lo, double hi, int n, unsigned long long *
   if (__double_as_longlong(s0) != __double_as_longlong(s1) || __double_as_longlong(c0) != __double_as_longlong(c1))
     atomicAdd(mism, 1ull);
 }
+
+#endif  // SVSDF_API_TU
 
 // per-lane cache of the current piece and its [S_lo, S_hi] interval (avoids the LDS walk when
 // consecutive evaluations stay in one piece, which is the rule in the scan layers and the descent)
@@ -309,6 +312,7 @@ __device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp,
   return sdf_from_pose<SHAPE>(sp, p, px, py);
 }
 
+#ifdef SVSDF_API_TU   // shape-independent kernel: compiled once, by svsdf_api.hip
 // ---------------------------------------------------------------------------------------------
 // k_prep: one block.  in = [coeffs (6N x 3 column-major) | T (N) | tk (K)] as uploaded.
 // Also clears the per-batch control blocks for this evaluation.
@@ -361,6 +365,8 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     chunks[c] = ch;
   }
 }
+
+#endif  // SVSDF_API_TU
 
 // Shape bound radius: max over a polar grid of |q| - sdf_shape(q) (body frame, including the
 // shape's own offset/rotation).  For an exact SDF this is the circumradius about the origin.
@@ -1299,6 +1305,7 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
   }
 }
 
+#ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_api.hip
 __global__ void __launch_bounds__(kBlock)
 k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
@@ -1523,5 +1530,7 @@ k_points_gather(const double *__restrict__ xyz, const unsigned long long *__rest
     idx_out[j] = (long long)i;
   }
 }
+
+#endif  // SVSDF_API_TU
 
 }  // namespace svsdf

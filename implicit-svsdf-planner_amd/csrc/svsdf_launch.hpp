@@ -1,0 +1,55 @@
+// svsdf_launch.hpp -- host-side launchers of the shape-templated kernels.
+//
+// The kernels are specialised per shape id (17 shapes x lane-group widths x GSIP bound modes: ~250 kernels).  They are
+// compiled in SVSDF_NSLICES translation units (svsdf_shape_slice.hip with -DSVSDF_SLICE=k holds the shapes with
+// id % SVSDF_NSLICES == k) so that the build runs in parallel; svsdf_api.hip only sees these plain functions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "svsdf_kernels.hpp"
+#include "svsdf_frontend.hpp"
+
+namespace svsdf {
+
+constexpr int kNSlices = 4;
+
+struct SolveLaunch {   // arguments of k_solve<SHAPE, G, 1>
+  const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; QuerySet qs;
+  double *out_sdf, *out_t; int prune; BatchCtl *ctl; int work_idx; double cull_thresh;
+};
+struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
+  const TrajDev *traj; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py; GsipState gs;
+  size_t stride; int it; double delta, band_delta; double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl;
+};
+struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
+  const TrajDev *traj; ShapeParams sp; const double *px, *py, *sdf, *t; double *res_sdf, *res_t, *res_gx, *res_gy;
+  GsipState gs; BatchCtl *ctl;
+};
+
+// each returns false when the shape id is not compiled into the library (development builds)
+bool launch_k_solve(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a);
+bool launch_k_round(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a);
+bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a);
+bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out);
+bool launch_k_subsw(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,
+                    const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);
+bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu,
+                            int size_side, double safemargin, const double *yaw, unsigned char *map);
+
+// per-slice entry points (defined by svsdf_shape_slice.hip, one set per slice)
+#define SVSDF_DECLARE_SLICE(K)                                                                                              \
+  bool launch_k_solve_s##K(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a); \
+  bool launch_k_round_s##K(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a);      \
+  bool launch_k_classify_s##K(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a);                  \
+  bool launch_k_rbound_s##K(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out); \
+  bool launch_k_subsw_s##K(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,    \
+                           const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);         \
+  bool launch_k_shape_kernels_s##K(int shape, unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu,   \
+                                   int size_side, double safemargin, const double *yaw, unsigned char *map);
+SVSDF_DECLARE_SLICE(0)
+SVSDF_DECLARE_SLICE(1)
+SVSDF_DECLARE_SLICE(2)
+SVSDF_DECLARE_SLICE(3)
+#undef SVSDF_DECLARE_SLICE
+
+}  // namespace svsdf
