@@ -363,6 +363,25 @@ def main():
                                   "ms_combine_inprocess: host time from 'all devices done' to 'summed partial on the host'"}
     # release the headline workload before the sub-runs
     r.opt._ctx.close()
+    if multi and not a.no_extras:
+        # strong-scaling base measured in the same run: the same total cloud on ONE GPU (rank 0's / the first device),
+        # so that the speed-up of this line does not have to be inferred from the N = 1 line of another workload
+        import svsdf_amd
+        c1 = svsdf_amd.SvsdfContext(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
+                                    poly_params=w["poly_params"], polygon=w["polygon"], head_state=w["head_state"],
+                                    tail_state=w["tail_state"], device=(devices[0] if devices else local_rank))
+        c1.set_points(w["points"])
+        for _ in range(3):
+            c1.eval_penalty(w["coeffs"], w["T"])
+        nb = max(3, min(a.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            c1.eval_penalty(w["coeffs"], w["T"])
+        base_ms = 1e3 * (time.perf_counter() - t0) / nb
+        c1.close()
+        res["strong_scaling_base"] = {"n_gpus": 1, "points_total": P_total, "steps": nb, "ms_per_step": base_ms,
+                                      "value": P_total / (base_ms * 1e-3), "speedup_of_this_line": base_ms / ms_per_step,
+                                      "note": "same workload, whole cloud resident on one GPU, measured by rank 0 after the timed region"}
     if not multi and not a.no_extras and a.config is None and a.points is None and a.dist == "corridor":
         res["north_star"] = sub_run(a, "NS", workload.CONFIGS["NS"]["P"], "corridor", rank, world, local_rank, None, None, a.extra_steps)
         res["map_distribution"] = sub_run(a, name, P_total, "map", rank, world, local_rank, None, None, a.extra_steps)

@@ -186,6 +186,7 @@ def test_bench_c4_inprocess_two_stripes(built):
     assert r["n_gpus"] == 2 and r["config"]["points_total"] == 4000000 and r["scaling"] == "strong"
     assert r["config"]["points_per_gpu"] == 2000000 and r["value"] > 0
     assert r["combine"]["ms_combine_inprocess"] is not None and r["combine"]["ms_combine_inprocess"] < 1.0
+    assert r["strong_scaling_base"]["points_total"] == 4000000 and r["strong_scaling_base"]["ms_per_step"] > 0
 
 
 @pytest.mark.gpu
@@ -201,3 +202,4 @@ def test_bench_c4_two_ranks_emulated(built):
     r = _bench(["--gpus", "2", "--config", "C4", "--points", "400000", "--steps", "2", "--warmup", "1"], env, launcher)
     assert r["n_gpus"] == 2 and r["config"]["points_total"] == 400000 and r["config"]["points_per_gpu"] == 200000
     assert r["scaling"] == "strong" and r["value"] > 0
+    assert r["strong_scaling_base"]["speedup_of_this_line"] > 0
