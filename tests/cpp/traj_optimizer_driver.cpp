@@ -2,8 +2,10 @@
 // optimize_traj_lmbm drives TrajOptimizer: a raw lmbm_evaluate_t function pointer + void* instance.
 // Input (stdin): shape_inputdata safety_hor weight_p rho N P, then 9+9 state doubles, n x-doubles,
 // 3P point doubles.  Output: cost, cost_pos, cost_other, cost_total, then g[0..n); with --optimize also
-// ret, iterations, final cost, cost_total and the optimised x[0..n).
+// ret, iterations, final cost, cost_total and the optimised x[0..n).  `--devices 0,1,...` makes the ONE TrajOptimizerHip
+// of this process drive several GPUs (svsdf_config::n_devices; a device may repeat: several stripes on one GPU).
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -28,8 +30,21 @@ int main(int argc, char **argv) {
   std::vector<double> x(n), g(n), pts(3 * (size_t)P);
   for (double &v : x) if (std::scanf("%lf", &v) != 1) return 2;
   for (double &v : pts) if (std::scanf("%lf", &v) != 1) return 2;
+  std::vector<int> devices;
+  for (int a = 1; a + 1 < argc; ++a)
+    if (std::string(argv[a]) == "--devices") {
+      const std::string list = argv[a + 1];
+      size_t pos = 0;
+      while (pos < list.size()) {
+        size_t e = list.find(',', pos);
+        if (e == std::string::npos) e = list.size();
+        devices.push_back(std::atoi(list.substr(pos, e - pos).c_str()));
+        pos = e + 1;
+      }
+    }
   svsdf::TrajOptimizerHip opt;
   opt.inputdata = name; opt.safety_hor = sh; opt.weight_p = wp; opt.rho = rho; opt.device = 0;
+  opt.devices = devices;
   opt.setConditions(hs, ts, N);
   opt.setPoints(pts.data(), (size_t)P);
   lmbm_evaluate_t eval = &svsdf::TrajOptimizerHip::costFunctionLmbmParallel;

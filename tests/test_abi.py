@@ -53,3 +53,28 @@ def test_product_does_not_touch_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liborc" not in txt and "svsdf_oracle" not in txt and "from oracle" not in txt \
                     and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_set_conditions_on_a_host_only_context(built):
+    """svsdf_set_conditions changes the boundary states in place: the host half of the callback (MINCO forward) sees
+    them on the next call, without a new context."""
+    import numpy as np
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make("C1", P=10)
+    x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+    ctx = svsdf_amd.SvsdfContext(shape="star", head_state=w["head_state"], tail_state=w["tail_state"],
+                                 flags=svsdf_amd.FLAG_HOST_ONLY)
+    c0, T0 = ctx.lmbm_prepare(x)
+    hs = w["head_state"].copy()
+    hs[1, 0] += 0.75
+    ctx.set_conditions(hs, w["tail_state"])
+    c1, T1 = ctx.lmbm_prepare(x)
+    ref = svsdf_amd.minco_coeffs(hs, w["tail_state"], w["q"], T1)
+    np.testing.assert_array_equal(T0, T1)
+    np.testing.assert_allclose(c1, ref, rtol=0, atol=1e-12)
+    assert abs(c1[0, 1] - (c0[0, 1] + 0.75)) < 1e-12        # constant term of piece 0, y: the new start position
+    bad = hs.copy(); bad[0, 0] = np.nan
+    import pytest
+    with pytest.raises(svsdf_amd.SvsdfError):
+        ctx.set_conditions(bad, w["tail_state"])
