@@ -175,7 +175,17 @@ class Runner:
             solve_ms += st["solve_ms"]
             dev_ms += st["device_ms"]
             self.solve_ms_sum += st["solve_ms_sum"] / steps
+        # the same with the point batches run one after the other: a launch's duration is then its own cost
+        self.ctx.set_profiling(2)
+        self.solve_ms_serial = self.dev_ms_serial = 0.0
+        self.step()
+        for _ in range(steps):
+            self.step()
+            st = self.ctx.stats()
+            self.solve_ms_serial += st["solve_ms"] / steps
+            self.dev_ms_serial += st["device_ms"] / steps
         self.ctx.set_profiling(False)
+        self.step()
         return solve_ms / steps, dev_ms / steps
 
     def full_callback(self, steps, perturb=0.0, seed=7):
@@ -348,11 +358,16 @@ def main():
                                          "during which at least one k_solve launch was executing (merged HIP-event intervals; "
                                          "what `achieved` divides by), kernel_ms_sum_per_step = plain sum of the launch durations "
                                          "(what a rocprofv3 kernel trace adds up: launches x average duration)",
+                     "kernel_ms_serialized_per_step": r.solve_ms_serial, "device_ms_serialized_per_step": r.dev_ms_serial,
+                     "serialized_note": "the same evaluation with the batches run one after the other (svsdf_set_profiling 2; "
+                                        "what `SVSDF_BATCHES=1` gives): k_solve's own cost per evaluation, comparable with a "
+                                        "kernel trace taken that way (profiles/*_b1_kernel_stats.csv) and with round 1",
                      "launches_per_step": acc["solve_launches"] / a.steps,
                      "device_ms_per_step": dev_ms_step, "profiled_steps": prof_steps,
                      "note": "24 B/point algorithmic; the solve is FP64-VALU bound (SURVEY.md §8d), see fp64",
                      "fp64": {"bound": "fp64_valu", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_tf / FP64_PEAK_TFLOPS,
+                              "frac_serialized": ach_tf * solve_ms_step / max(r.solve_ms_serial, 1e-9) / FP64_PEAK_TFLOPS,
                               "sdf_evals_per_step": evals_all / a.steps, "layer1_evals_per_step": scan_all / a.steps,
                               "flop_per_eval_nominal": FLOP_PER_EVAL}},
     }

@@ -161,6 +161,7 @@ struct svsdf_ctx {
 
   // profiling
   bool profile = false;  // per-launch HIP events (env SVSDF_PROFILE=1 or svsdf_set_profiling)
+  int saved_nbatch = 0;  // svsdf_set_profiling(ctx, 2): the batch split to restore
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, size_t>> refine_events;  // (start, stop) indices into ev_pool
@@ -1525,8 +1526,27 @@ long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, in
 
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
   if (!ctx) return SVSDF_ERR_INVALID;
+  if (!ctx->subs.empty()) {
+    int rc = SVSDF_OK;
+    for (svsdf_ctx *s : ctx->subs) { const int r = svsdf_set_profiling(s, enable); if (r && !rc) rc = r; }
+    ctx->profile = enable != 0;
+    return rc;
+  }
   ctx->profile = enable != 0;
-  for (svsdf_ctx *s : ctx->subs) s->profile = enable != 0;
+  if (ctx->host_only) return SVSDF_OK;
+  // enable == 2: also run the point batches one after the other (one batch) while profiling, so that every launch's
+  // duration is its own cost and not stretched by the kernels of the other batches it normally overlaps with
+  if (enable == 2 && ctx->nbatch > 1 && ctx->points_set) {
+    ctx->saved_nbatch = ctx->nbatch;
+    HIPCHK(hipSetDevice(ctx->device));
+    return set_batches(ctx, 1);
+  }
+  if (enable != 2 && ctx->saved_nbatch > 0 && ctx->points_set) {
+    const int nb = ctx->saved_nbatch;
+    ctx->saved_nbatch = 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    return set_batches(ctx, nb);
+  }
   return SVSDF_OK;
 }
 

@@ -512,7 +512,7 @@ class SvsdfContext:
         return float(o[0]), float(o[1])
 
     def set_profiling(self, enable=True):
-        self._chk(self.L.svsdf_set_profiling(self.ctx, int(bool(enable))), "svsdf_set_profiling")
+        self._chk(self.L.svsdf_set_profiling(self.ctx, int(enable)), "svsdf_set_profiling")   # 2: serialised batches
 
     def stats(self):
         s = Stats()

@@ -318,8 +318,11 @@ int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
  * (analytic circumradius of the shape + |offset|, Shape.hpp:281-294 / :531-1476), out2[1] = the largest
  * |q| - sdf_shape(q) found on a polar grid out to 60 m at context creation (self-check: <= out2[0]). */
 int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]);
-/* Per-launch HIP-event timing of the dominant (argmin refine) kernel on the library's own
- * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms. */
+/* Per-launch HIP-event timing of the dominant (argmin solve) kernel on the library's own
+ * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms / solve_ms_sum.
+ * enable = 2: additionally runs the point batches one after the other while profiling (a single batch), so that a
+ * launch's duration is its own cost rather than stretched by the other batches' kernels it normally overlaps with;
+ * enable = 0 restores the split. */
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable);
 /* Self-check: number of n equispaced arguments in [lo, hi] for which the kernels' inlined sincos
  * differs by even one bit from the ROCm device library's sincos (must be 0); -1 on error. */

@@ -19,9 +19,15 @@ KS=$(find $OUT/${TAG}_kt -name '*kernel_stats.csv' | head -1); cp $KS $OUT/${TAG
 F=$(find $OUT/${TAG}_pmc_f -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/${TAG}_pmc_w -name '*counter_collection.csv' | head -1)
 S=$(find $OUT/${TAG}_pmc_s -name '*counter_collection.csv' | head -1)
-# evaluations per profiled run: 2 settle + 1 warm-up + 5 timed + 5 event-profiled + 2 full-callback passes (1 + 5 each... see bench.py)
-python $ROOT/tools/pmc_summary.py $F $W $S ${3:-25} "rocprofv3 PMC summary, bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-extras, 1x MI355X, $TAG" > $OUT/${TAG}_bench_${CFG}_pmc_summary.txt
+# evaluations per profiled run: 2 settle + 1 warm-up + 5 timed + 5 event-profiled + 7 serialised-profiled + 12 full-callback = 32
+python $ROOT/tools/pmc_summary.py $F $W $S ${3:-32} "rocprofv3 PMC summary, bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-extras, 1x MI355X, $TAG" > $OUT/${TAG}_bench_${CFG}_pmc_summary.txt
 KT=$(find $OUT/${TAG}_kt -name '*kernel_trace.csv' | head -1)
 python $ROOT/tools/timeline.py $KT 6 > $OUT/${TAG}_bench_${CFG}_timeline.txt 2>&1
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_s
 tail -c 300 $OUT/${TAG}_bench_${CFG}_short.json
+# the same kernel trace with the point batches run one after the other: per-launch durations are then each kernel's own cost
+SVSDF_BATCHES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt1 -o kt -- $BENCH > $OUT/${TAG}_kt1.log 2>&1
+KS1=$(find $OUT/${TAG}_kt1 -name '*kernel_stats.csv' | head -1); cp $KS1 $OUT/${TAG}_bench_${CFG}_b1_kernel_stats.csv
+KT1=$(find $OUT/${TAG}_kt1 -name '*kernel_trace.csv' | head -1)
+python $ROOT/tools/timeline.py $KT1 6 > $OUT/${TAG}_bench_${CFG}_b1_timeline.txt 2>&1
+rm -rf $OUT/${TAG}_kt1
