@@ -840,7 +840,13 @@ int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, i
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipDeviceSynchronize());
   ws = std::max(1, ws);
+  // until the new cloud is completely in place the context holds none (a failed upload must not leave the old point
+  // count with re-allocated buffers)
+  ctx->P = 0;
+  ctx->points_set = false;
+  ctx->saved_nbatch = 0;
   const size_t Ps = (P > (size_t)rk) ? (P - (size_t)rk + (size_t)ws - 1) / (size_t)ws : 0;
+  if (P > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points (max 2^31 - 1 per call)");
   if (Ps * kMaxSlots > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard (max ~89M)");
   ctx->shard_idx.assign(Ps, 0ll);
   int rc = alloc_point_buffers(ctx, Ps);

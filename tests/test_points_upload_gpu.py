@@ -63,8 +63,10 @@ def test_nonfinite_points_are_rejected(built):
     for bad in (np.nan, np.inf, -np.inf):
         q = pts.copy(); q[517, 1] = bad
         c = svsdf_amd.SvsdfContext(shape="star", device=0)
+        c.set_points(pts)
         with pytest.raises(svsdf_amd.SvsdfError, match="non-finite"):
             c.set_points(q)
+        assert c.num_points() == 0            # a failed upload leaves no (stale) cloud behind
         c.set_points(pts)                     # still usable
         assert c.num_points() == 1000
         c.close()
