@@ -137,7 +137,9 @@ const char *svsdf_last_error_string(const svsdf_ctx *ctx); /* ctx may be NULL */
  * 168-175): P points, AoS xyz doubles (Eigen::Vector3d layout); z is ignored (BEO:790-791).
  * Copies; the cloud stays resident in HBM for all following evaluations. */
 int svsdf_set_points(svsdf_ctx *ctx, const double *xyz_aos, size_t P);
-/* Same, but xyz_aos is a DEVICE pointer on ctx's device (inputs already resident in HBM). */
+/* Same, but xyz_aos is a DEVICE pointer on ctx's device (devices[0] of a multi-device context): inputs already
+ * resident in HBM.  Both entry points plan the cloud on the device (bounding box -> Morton keys -> radix sort ->
+ * gather of this context's stripe); svsdf_shard_plan below is the same plan computed on the host. */
 int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P);
 size_t svsdf_num_points(const svsdf_ctx *ctx);        /* points owned by this rank's shard */
 /* Pure host: the original indices rank `rank` of `world_size` owns (Morton order, striped), in
