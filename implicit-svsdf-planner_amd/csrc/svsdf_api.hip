@@ -122,6 +122,12 @@ struct svsdf_ctx {
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
   bool block_env = false;      // env SVSDF_BLOCK pins the solve kernel's block size (default: by LDS footprint)
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
+  bool persistent = false;   // SVSDF_PERSISTENT=1: one k_gsip launch per batch instead of the k_solve / k_round chain
+  int gsip_blocks_per_cu = 0;   // resident blocks of k_gsip per CU (occupancy query, cached per block size / LDS / mode)
+  long long gsip_key[3] = {0, 0, -1};
+  int n_cu = 256;
+  int gsip_grace = 32;      // polls a wave waits for the rest of a reserved ticket once its first entry is there
+  int gsip_error = 0;        // k_gsip gave up (queue overflow / poll cap): the evaluation is rerun through the chain
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
   bool ub_lazy = false;        // with ub_full: only the samples in the cheap-bound band are scanned (k_round MODE 2)
@@ -189,7 +195,7 @@ struct svsdf_ctx {
 namespace {
 
 constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 9 + kMaxIter;
+constexpr size_t kOutDoubles = kOutPartial + 10 + kMaxIter;   // partial | 9 counters | solves per iteration | k_gsip error
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -266,6 +272,10 @@ bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, con
   shape = compiled_shape(shape);
   SVSDF_SLICE_DISPATCH(launch_k_classify, grid, lds, st, a)
 }
+bool launch_k_gsip(int shape, int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_gsip, mode, grid, block, lds, st, a)
+}
 bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out) {
   shape = compiled_shape(shape);
   SVSDF_SLICE_DISPATCH(launch_k_rbound, grid, st, sp, rmax, nrad, nang, out)
@@ -333,6 +343,40 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta,
                       band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
   (void)launch_k_round(ctx->cfg.shape_id, lp, mode, grid, lds, st, a);
+}
+
+// The whole GSIP loop of batch b in one persistent launch (k_gsip), after k_round(0) opened every point's first round.
+void launch_gsip(svsdf_ctx *ctx, hipStream_t st, int b) {
+  const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
+  const bool scans = mode != 0;
+  const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
+  const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
+  const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
+  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N)) * sizeof(double);
+  int blk = ctx->block;
+  if (!ctx->block_env) blk = (lds * 12 <= 160 * 1024) ? 64 : (lds * 6 <= 160 * 1024) ? 128 : 256;
+  const long long lanes = std::max<long long>((long long)ctx->bcount[b] * 8, 64);   // ~ 2 solves of 4 lanes per point
+  const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
+  // this batch's shards and rings (twice the batch's worst-case outstanding tasks + the shards' slack)
+  GsipState gsb = ctx->gs;
+  gsb.qsh = ctx->gs.qsh + (size_t)b * kMaxShards;
+  gsb.q = ctx->gs.q + 2 * (size_t)ctx->bstart[b] * kMaxSlots + (size_t)b * kMaxShards * kShardSlack;
+  hipLaunchKernelGGL(k_gsip_init, dim3(1), dim3(kMaxShards), 0, st, ctx->d_ctl + b, gsb.qsh);
+  if (ctx->gsip_key[0] != blk || ctx->gsip_key[1] != (long long)lds || ctx->gsip_key[2] != mode) {
+    ctx->gsip_key[0] = blk; ctx->gsip_key[1] = (long long)lds; ctx->gsip_key[2] = mode;
+    ctx->gsip_blocks_per_cu = 0;
+  }
+  size_t e0 = 0, e1 = 0;
+  if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
+  const GsipLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, gsb, ctx->P, sel,
+                     ctx->select_delta, all_it, ctx->gsip_grace, ctx->n_cu, &ctx->gsip_blocks_per_cu, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
+  (void)launch_k_gsip(ctx->cfg.shape_id, mode, grid, (unsigned)blk, lds, st, a);
+  if (ctx->profile) {
+    e1 = next_event(ctx);
+    (void)hipEventRecord(ctx->ev_pool[e1], st);
+    ctx->refine_events.emplace_back(e0, e1);
+  }
+  ctx->stats.solve_launches++;
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
@@ -529,9 +573,14 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0, cull_thresh);
     launch_classify(ctx, st, b);
     launch_round(ctx, st, b, 0);
+    if (ctx->persistent) launch_gsip(ctx, st, b);
   }
-  for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
-  ctx->it_done = ctx->first_iters;
+  if (ctx->persistent) {
+    ctx->it_done = 1;   // k_finish: n_solve[1] stays zero, nothing pending
+  } else {
+    for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
+    ctx->it_done = ctx->first_iters;
+  }
   return join_batches(ctx);
 }
 
@@ -572,6 +621,8 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   int rc = reduce_and_read(ctx, with_partial);
   if (rc) return rc;
   const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out + kOutPartial);
+  ctx->gsip_error = (int)st[9 + kMaxIter];
+  if (ctx->gsip_error) return SVSDF_OK;   // the caller reruns the evaluation through the launch chain
   while (st[5] > 0 && ctx->it_done < kMaxIter) {  // solves requested by the last k_round are pending
     const int it1 = std::min(ctx->it_done + 3, (int)kMaxIter);
     for (int it = ctx->it_done; it < it1; ++it) enqueue_solve_round(ctx, it);
@@ -588,11 +639,13 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.gsip_samples = st[6];
   ctx->stats.gsip_iterations = (unsigned)st[7];
   ctx->stats.culled_points = st[8];
-  for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
-  ctx->have_prev_nsolve = true;
+  if (!ctx->persistent) {
+    for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
+    ctx->have_prev_nsolve = true;
+  }
   // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
   // covers an underestimate
-  if (ctx->adaptive_iters) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
+  if (ctx->adaptive_iters && !ctx->persistent) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
   if (ctx->profile) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
@@ -622,24 +675,28 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
     ctx->stats.solve_ms = uni;
     ctx->stats.solve_ms_sum = sum;
   }
-#ifdef SVSDF_TIMING
-  if (std::getenv("SVSDF_DUMP_TIMING")) {
-    std::vector<unsigned long long> tm(8 * (kMaxIter + 4));
-    (void)hipMemcpy(tm.data(), reinterpret_cast<char *>(ctx->d_ctl) + kMaxBatches * sizeof(BatchCtl), tm.size() * 8, hipMemcpyDeviceToHost);
-    (void)hipMemset(reinterpret_cast<char *>(ctx->d_ctl) + kMaxBatches * sizeof(BatchCtl), 0, tm.size() * 8);
-    for (int w = 0; w < kMaxIter + 2; ++w) {
-      const unsigned long long *t = &tm[8 * w];
-      if (!t[5]) continue;
-      std::fprintf(stderr, "[timing] launch %2d: waves %6llu  avg us/wave: scan %7.1f layers %7.1f gd %7.1f life %7.1f  max life %7.1f  gd steps/wave %6.1f\n",
-                   w, t[5], t[0] / 100.0 / t[5], t[1] / 100.0 / t[5], t[2] / 100.0 / t[5], t[3] / 100.0 / t[5], t[6] / 100.0, (double)t[4] / t[5]);
-    }
-  }
-#endif
   if (st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
 }
 
 int set_batches(svsdf_ctx *ctx, int nb);   // below
+
+// One evaluation up to the per-point results (and the partial): enqueue, finish; when the persistent GSIP kernel gave
+// up (it never should: the queues hold the worst case) the evaluation is repeated through the launch chain and the
+// context stays on the chain.
+int evaluate_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bool allow_cull, bool with_partial) {
+  int rc = enqueue_queries(ctx, N, coeffs, T, allow_cull);
+  if (rc) return rc;
+  rc = finish(ctx, with_partial);
+  if (rc == SVSDF_OK && ctx->gsip_error) {
+    std::fprintf(stderr, "[svsdf] persistent GSIP kernel gave up (code %d); falling back to the launch chain\n", ctx->gsip_error);
+    ctx->persistent = false;
+    ctx->gsip_error = 0;
+    if ((rc = enqueue_queries(ctx, N, coeffs, T, allow_cull))) return rc;
+    rc = finish(ctx, with_partial);
+  }
+  return rc;
+}
 
 void fill_mode_stats(svsdf_ctx *ctx) {
   ctx->stats.gsip_bound_mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
@@ -690,9 +747,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   // evaluations and without depending on the box.)
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
   if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; }
-  int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/true);
-  if (rc) return rc;
-  rc = finish(ctx, true);
+  int rc = evaluate_points(ctx, N, coeffs, T, /*allow_cull=*/true, /*with_partial=*/true);
   if (rc == SVSDF_OK && deciding) {
     const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
     const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
@@ -707,7 +762,8 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
-    if (ctx->ub_full && ctx->want_batches == 0 && large) rc = set_batches(ctx, ctx->ub_lazy ? 2 : 4);
+    // (the persistent GSIP kernel has no per-iteration tails for a second batch to fill: it keeps one batch)
+    if (ctx->ub_full && ctx->want_batches == 0 && large && !ctx->persistent) rc = set_batches(ctx, ctx->ub_lazy ? 2 : 4);
   }
   fill_mode_stats(ctx);
   ctx->h_partial = ctx->h_out;
@@ -741,6 +797,8 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.phase, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[0], P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[1], P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->gs.pending, P))) return rc;
+
   const size_t S = P * kMaxSlots;
   if ((rc = dev_alloc(ctx, &ctx->gs.solve, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sqx, S))) return rc;
@@ -750,6 +808,12 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_k, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_sdf, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_t, S))) return rc;
+  if (ctx->persistent) {   // task rings of k_gsip: zero = free slot (the kernel leaves them zeroed)
+    const size_t R = 2 * S + (size_t)kMaxBatches * kMaxShards * kShardSlack;
+    if ((rc = dev_alloc(ctx, &ctx->gs.q, R))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->gs.qsh, (size_t)kMaxBatches * kMaxShards))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->gs.q, 0, R * sizeof(unsigned long long), ctx->stream));
+  }
   return SVSDF_OK;
 }
 
@@ -1301,6 +1365,12 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) { ctx->delta_all_iter = std::atoi(e); ctx->all_iter_env = true; }
   if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) { ctx->select_delta = std::atof(e); ctx->select_env = true; }
+  if (const char *e = std::getenv("SVSDF_PERSISTENT")) ctx->persistent = std::atoi(e) != 0;
+  {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n > 0) ctx->n_cu = n;
+  }
+  if (const char *e = std::getenv("SVSDF_GSIP_GRACE")) ctx->gsip_grace = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
@@ -1377,7 +1447,8 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs.pt,
                   ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.phase,
                   ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
-                  ctx->gs.sq_ub, ctx->gs.sq_k, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl, ctx->d_block_partials, ctx->d_sums,
+                  ctx->gs.sq_ub, ctx->gs.sq_k, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->gs.pending, ctx->gs.q, ctx->gs.qsh, ctx->d_ctl,
+                  ctx->d_block_partials, ctx->d_sums,
                   ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_flag};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
@@ -1499,9 +1570,7 @@ int svsdf_query_points(svsdf_ctx *ctx, int N, const double *coeffs, const double
   if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
   if (!ctx->points_set) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
   if (ctx->P == 0) return SVSDF_OK;
-  int rc = enqueue_queries(ctx, N, coeffs, T, /*allow_cull=*/false);  // per-point outputs need every solve
-  if (rc) return rc;
-  rc = finish(ctx, false);
+  int rc = evaluate_points(ctx, N, coeffs, T, /*allow_cull=*/false, /*with_partial=*/false);  // per-point outputs need every solve
   if (rc) return rc;
   fill_mode_stats(ctx);
   const size_t P = ctx->P;

@@ -71,6 +71,9 @@ struct BatchCtl {
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
   int pad;
+  // queues of the persistent GSIP kernel (k_gsip): SOLVE tasks = sample slots in gs.solve, ROUND tasks = interior indices
+  unsigned q_done;   // persistent GSIP kernel: points finished
+  int q_error;
   unsigned long long stat_solves, stat_evals, stat_scan, stat_culled;
 };
 
@@ -328,6 +331,8 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     for (int r = 0; r < kMaxIter + 2; ++r) { c.n_active[r] = 0; c.n_solve[r] = 0; c.n_seed[r] = 0; }
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
     c.nonfinite = 0;
+    c.q_done = 0u;
+    c.q_error = 0;
     c.stat_solves = 0ull; c.stat_evals = 0ull; c.stat_scan = 0ull; c.stat_culled = 0ull;
   }
   if (threadIdx.x == 0) {
@@ -596,84 +601,18 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_solve: getSDFofSweptVolume<false,true> (SWM:844-866) without its FD gradient, for the main
-// points of a batch or for the selected GSIP circle samples.
-//  * choiceTInit layer 1 (SWM:549-576, first pass): poses at the scan times do not depend on the
-//    query point, so they come from the table k_prep built (LDS) and a query only does the rigid
-//    transform + shape SDF per sample.  Chunks of 8 samples whose lower bound exceeds the running
-//    minimum are skipped: exact, a skipped sample can never be (or tie with) the minimum the
-//    reference's strict `<` scan keeps.
-//  * layers 2-4 (SWM:557-577) and gradientDescent (SWM:1249-1325): the 21 samples of a layer and
-//    the <= 29 candidates of a halving ladder are evaluated G at a time.  A ladder's candidates do
-//    not depend on each other, so the first accepted one is exactly the one the sequential loop
-//    accepts (bit-identical result, shorter dependent chain).  getSDF_DOT (SWM:799-806) is
-//    evaluated once per descent pass: x does not change inside the ladder, so the reference's
-//    per-trial re-evaluation returns the same number.
-// LDS: [pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
-// ---------------------------------------------------------------------------------------------
+// Layers 2-4 of choiceTInit (SWM:557-577) + gradientDescent (SWM:1249-1325) for ONE query by G cooperating lanes,
+// from the layer-1 seed (time tk[best_k], value best_d): the argmin time x and its value fx (all lanes of the group get
+// them).  Shared by k_solve and the persistent GSIP kernel.
 template <int SHAPE, int G, int U>
-__global__ void __launch_bounds__(kBlock, SVSDF_SOLVE_WAVES)
-k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
-        const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
-        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh) {
-  extern __shared__ double solve_lds[];
-  int n;
-  const long long total = qs_total(qs, n);
-  if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
-  const int K = trg->K;
-  const int nch = (K + kChunk - 1) / kChunk;
-  Pose *pose = reinterpret_cast<Pose *>(solve_lds);
-  Chunk *chunks = reinterpret_cast<Chunk *>(solve_lds + 4 * (size_t)K);
-  {
-    const double *src = reinterpret_cast<const double *>(pose_g);
-    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) solve_lds[i] = src[i];
-    const double *srcc = reinterpret_cast<const double *>(chunks_g);
-    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) solve_lds[4 * (size_t)K + i] = srcc[i];
-  }
-  const TrajL tr = stage_traj(trg, solve_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
+__device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
+                                                  double px, double py, int best_k, double best_d, double &x_out,
+                                                  double &fx_out, unsigned &n_eval) {
   const int li = Grp<G>::li();
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
-  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0;
-#ifdef SVSDF_TIMING
-  long long tm_scan = 0, tm_lay = 0, tm_gd = 0, tm_steps = 0, tm_start = wall_clock64();
-#endif
-  for (int guard = 0; guard < (1 << 26); ++guard) {
-    long long wave_base;
-    const long long gq = fetch_work<G>(&ctl->work[work_idx], wave_base);
-    if (wave_base >= total) break;
-#ifdef SVSDF_TIMING
-    const long long tq0 = wall_clock64();
-#endif
-    double px = 0.0, py = 0.0;
-    size_t slot = 0;
-    bool live = gq < total;
-    if (live) live = qs_slot(qs, n, gq, slot);
-    if (live) {
-      px = qs.qx[slot]; py = qs.qy[slot];
-      live = (px == px);  // NaN marks an unused slot (whole group)
-    }
-    if (live) {
-    // ---- choiceTInit layer 1 over the pose table (or the seed k_round already found for a GSIP sample)
-    double best_d = 1e9;
-    int best_k = 0x7fffffff;
-    bool culled = false;
-    if (qs.seed_k) {
-      best_k = qs.seed_k[slot];
-      best_d = qs.seed_d[slot];
-    }
-    if (!qs.seed_k || best_k < 0) {   // no seed for this query (main points, cheap-bound samples, unscanned lazy samples)
-      scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan);
-    }
-    if (culled) {
-      if (li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
-    } else {
     PieceCache piece = piece_cache_init();
     double time_seed = tk[best_k];
     double min_dis = best_d;
-#ifdef SVSDF_TIMING
-    const long long tq1 = wall_clock64();
-#endif
 
     // ---- choiceTInit layers 2-4: W = G*U samples per step, lane li takes li, li+G, ...
     constexpr int W = G * U;
@@ -720,9 +659,6 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       dt *= 0.1;
     }
 
-#ifdef SVSDF_TIMING
-    const long long tq2 = wall_clock64();
-#endif
     // ---- gradientDescent
     const double t_min = dmax(0.0, time_seed - 3.4);
     const double t_max = dmin(time_seed + 3.4, tr.dur);
@@ -756,9 +692,6 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       prev_x = x;
       bool accepted = false;
       for (int j0 = 1; j0 <= 29 && !accepted; j0 += W) {
-#ifdef SVSDF_TIMING
-        ++tm_steps;
-#endif
         double xc[U], fc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -790,27 +723,85 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       }
       if (!accepted) stop = true;
     }
+    x_out = x;
+    fx_out = fx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_solve: getSDFofSweptVolume<false,true> (SWM:844-866) without its FD gradient, for the main
+// points of a batch or for the selected GSIP circle samples.
+//  * choiceTInit layer 1 (SWM:549-576, first pass): poses at the scan times do not depend on the
+//    query point, so they come from the table k_prep built (LDS) and a query only does the rigid
+//    transform + shape SDF per sample.  Chunks of 8 samples whose lower bound exceeds the running
+//    minimum are skipped: exact, a skipped sample can never be (or tie with) the minimum the
+//    reference's strict `<` scan keeps.
+//  * layers 2-4 (SWM:557-577) and gradientDescent (SWM:1249-1325): the 21 samples of a layer and
+//    the <= 29 candidates of a halving ladder are evaluated G at a time.  A ladder's candidates do
+//    not depend on each other, so the first accepted one is exactly the one the sequential loop
+//    accepts (bit-identical result, shorter dependent chain).  getSDF_DOT (SWM:799-806) is
+//    evaluated once per descent pass: x does not change inside the ladder, so the reference's
+//    per-trial re-evaluation returns the same number.
+// LDS: [pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
+// ---------------------------------------------------------------------------------------------
+template <int SHAPE, int G, int U>
+__global__ void __launch_bounds__(kBlock, SVSDF_SOLVE_WAVES)
+k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
+        const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
+        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh) {
+  extern __shared__ double solve_lds[];
+  int n;
+  const long long total = qs_total(qs, n);
+  if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
+  const int K = trg->K;
+  const int nch = (K + kChunk - 1) / kChunk;
+  Pose *pose = reinterpret_cast<Pose *>(solve_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(solve_lds + 4 * (size_t)K);
+  {
+    const double *src = reinterpret_cast<const double *>(pose_g);
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) solve_lds[i] = src[i];
+    const double *srcc = reinterpret_cast<const double *>(chunks_g);
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) solve_lds[4 * (size_t)K + i] = srcc[i];
+  }
+  const TrajL tr = stage_traj(trg, solve_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
+  const int li = Grp<G>::li();
+  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0;
+  for (int guard = 0; guard < (1 << 26); ++guard) {
+    long long wave_base;
+    const long long gq = fetch_work<G>(&ctl->work[work_idx], wave_base);
+    if (wave_base >= total) break;
+    double px = 0.0, py = 0.0;
+    size_t slot = 0;
+    bool live = gq < total;
+    if (live) live = qs_slot(qs, n, gq, slot);
+    if (live) {
+      px = qs.qx[slot]; py = qs.qy[slot];
+      live = (px == px);  // NaN marks an unused slot (whole group)
+    }
+    if (live) {
+    // ---- choiceTInit layer 1 over the pose table (or the seed k_round already found for a GSIP sample)
+    double best_d = 1e9;
+    int best_k = 0x7fffffff;
+    bool culled = false;
+    if (qs.seed_k) {
+      best_k = qs.seed_k[slot];
+      best_d = qs.seed_d[slot];
+    }
+    if (!qs.seed_k || best_k < 0) {   // no seed for this query (main points, cheap-bound samples, unscanned lazy samples)
+      scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan);
+    }
+    if (culled) {
+      if (li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
+    } else {
+    double x = 0.0, fx = 0.0;
+    descend_from_seed<SHAPE, G, U>(tr, tk, sp, px, py, best_k, best_d, x, fx, n_eval);
     if (li == 0) {
       out_sdf[slot] = fx;
       out_t[slot] = x;
       ++n_solved;
     }
-#ifdef SVSDF_TIMING
-    { const long long tq3 = wall_clock64(); tm_scan += tq1 - tq0; tm_lay += tq2 - tq1; tm_gd += tq3 - tq2; }
-#endif
     }  // !culled
     }  // live
   }
-#ifdef SVSDF_TIMING
-  if ((threadIdx.x & 63) == 0) {
-    // wall_clock64 ticks at 100 MHz; [scan, layers, gd, total wave life, gd steps, waves]
-    unsigned long long *tmo = reinterpret_cast<unsigned long long *>(ctl + kMaxBatches) + 8 * work_idx;
-    atomicAdd(&tmo[0], (unsigned long long)tm_scan); atomicAdd(&tmo[1], (unsigned long long)tm_lay);
-    atomicAdd(&tmo[2], (unsigned long long)tm_gd); atomicAdd(&tmo[3], (unsigned long long)(wall_clock64() - tm_start));
-    atomicAdd(&tmo[4], (unsigned long long)tm_steps); atomicAdd(&tmo[5], 1ull);
-    atomicMax(&tmo[6], (unsigned long long)(wall_clock64() - tm_start));
-  }
-#endif
   unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tu = n_culled;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
@@ -830,6 +821,18 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 #define SVSDF_LAZY_REPS 2   // scan passes of the lazy bound mode: the band, then its extension (a third changes nothing)
 #endif
 enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
+// one shard of the persistent GSIP kernel's task queue (k_gsip), in its own cache line
+struct QShard { unsigned head, reserve, stop, pad[29]; };
+constexpr int kMaxShards = 256;
+constexpr unsigned kShardSlack = 2048;
+// ring slots per shard: twice an even share of the tasks that can be outstanding (kMaxSlots per point) plus a slack
+__host__ __device__ __forceinline__ unsigned gsip_shard_slots(int count, int nq) {
+  return (unsigned)((2ull * (unsigned long long)count * kMaxSlots) / (unsigned long long)nq) + kShardSlack;
+}
+// ring slots of a batch (any shard count)
+__host__ __device__ __forceinline__ size_t gsip_ring_slots(size_t count) {
+  return 2 * count * kMaxSlots + (size_t)kMaxShards * kShardSlack;
+}
 struct GsipState {
   int *pt;          // index of the (sorted) main point
   double *r;        // current circle radius
@@ -843,6 +846,10 @@ struct GsipState {
   // sample slots [j * stride + batch start + a]
   double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
   int *sq_k;        // layer-1 seed index of the sample (full-scan mode: sq_ub is then the seed value)
+  int *pending;     // per interior point: solves of the current round still outstanding (persistent GSIP kernel)
+  unsigned long long *q;   // task rings of the persistent GSIP kernel (this batch's shards one after the other), all zero
+                           // between evaluations
+  QShard *qsh;             // this batch's queue shards
 };
 
 // Per main point after the first solve: exterior -> FD gradient (getGradPrelAtTimeStamp,
@@ -925,6 +932,319 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
 // Opening a round: SampleSet2D::getElements / getElementPos (SWM:36-39, 60-71; one ring rk = 1)
 // with theta_j = theta0 + j * theta_res by repeated addition; expandSet(2, theta*) (SWM:105-110).
 // ---------------------------------------------------------------------------------------------
+// One GSIP step of ONE interior point (index a of its batch) by its LP lanes: close the round whose samples were solved
+// (or request supplementary solves), write the result when the point is finished, or open the next round (samples,
+// bounds, selection).  Outputs: which of this lane's samples are to be solved (list_me / mlist: per pass, the mask over
+// the point's lanes), whether the point stays active (push_next), samples emitted (n_emit), finished.  Shared by k_round
+// (one launch per GSIP iteration) and the persistent GSIP kernel (one ROUND task).
+// Global accesses of state that OTHER waves of the same launch write (persistent GSIP kernel only, COH = true): relaxed
+// agent-scope atomics, i.e. loads that do not hit a stale line of this XCD's L2 and write-through stores -- with these the
+// hand-overs need no cache-wide write-back / invalidate (an agent-scope fence costs tens of microseconds when thousands of
+// waves issue them), only the wave's own completion counter (workgroup-scope fence).  COH = false: plain accesses.
+template <bool COH, typename T>
+__device__ __forceinline__ T gld(const T *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ void gst(T *p, T v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <int NP>
+struct RoundOut {
+  bool list_me[NP];
+  unsigned mlist[NP];
+  int n_emit;
+  bool push_next, finished;
+};
+template <int SHAPE, int LP, int MODE, bool COH = false>
+__device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *pose, const Chunk *chunks, int K, int nch,
+                                            const double *__restrict__ px_, const double *__restrict__ py_,
+                                            const GsipState &gs, size_t stride, int start, int a, double delta,
+                                            double band_delta, double *__restrict__ res_sdf, double *__restrict__ res_t,
+                                            double *__restrict__ res_gx, double *__restrict__ res_gy, unsigned &n_scan,
+                                            RoundOut<(kMaxSlots + LP - 1) / LP> &out) {
+  constexpr bool FULL = MODE == 1;
+  constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
+  const int l = (int)(threadIdx.x & (LP - 1));
+  const unsigned lt_mask = (1u << l) - 1u;
+  auto ballot_g = [&](bool p) -> unsigned {   // bit i <=> lane i of this point's lane group
+    const unsigned long long m = __ballot(p);
+    const int base = (int)(threadIdx.x & 63) & ~(LP - 1);
+    return (unsigned)((m >> base) & ((LP == 32) ? 0xffffffffull : 0xffull));
+  };
+  bool (&list_me)[NP] = out.list_me;
+  unsigned (&mlist)[NP] = out.mlist;
+  bool &push_next = out.push_next;
+  int &n_emit = out.n_emit;
+  int i = 0;
+  size_t ia = 0;
+  bool open = false;
+  double cx = 0.0, cy = 0.0, r = 0.0, theta0 = 0.0, theta_res = 0.0;
+    ia = (size_t)start + a;
+    i = gs.pt[ia];
+    cx = px_[i]; cy = py_[i];
+    r = gld<COH>(&gs.r[ia]); theta0 = gld<COH>(&gs.theta0[ia]); theta_res = gld<COH>(&gs.theta_res[ia]);
+    open = gld<COH>(&gs.phase[ia]) == kPhaseNew;
+    if (!open) {
+      // ---- close the round: max over the solved samples, first index wins ties (strict >)
+      const int n = gld<COH>(&gs.nsamp[ia]);
+      double g_mine[NP];
+      double g = kUnsolved;
+      int idx = 0x7fffffff;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int j = l + LP * ps;
+        g_mine[ps] = (j < n) ? gld<COH>(&gs.sq_sdf[(size_t)j * stride + ia]) : kUnsolved;
+        if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
+      }
+      {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
+        auto step = [&](double og, int oi) { if (og > g || (og == g && oi < idx)) { g = og; idx = oi; } };
+        step(Grp<LP>::template xchg<0>(g), Grp<LP>::template xchg<0>(idx));
+        step(Grp<LP>::template xchg<1>(g), Grp<LP>::template xchg<1>(idx));
+        step(Grp<LP>::template xchg<2>(g), Grp<LP>::template xchg<2>(idx));
+        if constexpr (LP == 32) {
+          step(Grp<LP>::template xchg<3>(g), Grp<LP>::template xchg<3>(idx));
+          step(Grp<LP>::template xchg<4>(g), Grp<LP>::template xchg<4>(idx));
+        }
+      }
+      double max_g = -100000, real_t = gld<COH>(&res_t[i]), star_th = 0.0;
+      if (g > max_g) {
+        const size_t sb = (size_t)idx * stride + ia;
+        max_g = g; real_t = gld<COH>(&gs.sq_t[sb]); star_th = gld<COH>(&gs.sqth[sb]);
+      }
+      // unsolved samples that could still reach max_g -> supplementary solves
+      bool any = false;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int j = l + LP * ps;
+        list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gld<COH>(&gs.sq_ub[(size_t)j * stride + ia]) >= max_g;
+        mlist[ps] = ballot_g(list_me[ps]);
+        any = any || (mlist[ps] != 0u);
+      }
+      if (any) {
+        push_next = true;
+        if (l == 0) gst<COH>(&gs.phase[ia], (int)kPhaseSupp);
+      } else {
+        const double r_star = r - max_g;
+        const int iter = gld<COH>(&gs.iter[ia]);
+        if (iter > 8 || fabs(max_g) < 0.1) {
+          if (l == 0) {
+            const double corx = cx + 1.0 * r_star * cos(star_th);
+            const double cory = cy + 1.0 * r_star * sin(star_th);
+            double gx = corx - cx, gy = cory - cy;
+            const double z = gx * gx + gy * gy;
+            if (z > 0.0) { const double nn = sqrt(z); gx = gx / nn; gy = gy / nn; }
+            res_sdf[i] = -r_star; res_t[i] = real_t; res_gx[i] = gx; res_gy[i] = gy;
+          }
+          out.finished = true;
+        } else {
+          // expandSet(2, theta*)
+          theta_res = theta_res / (2 + 1);
+          theta_res = dmax(0.3, theta_res);
+          r = r_star;
+          theta0 = star_th;
+          if (l == 0) {
+            gst<COH>(&gs.r[ia], r); gst<COH>(&gs.theta_res[ia], theta_res); gst<COH>(&gs.theta0[ia], theta0);
+            gst<COH>(&gs.iter[ia], iter + 1);
+            gst<COH>(&res_t[i], real_t);
+          }
+          open = true;
+        }
+      }
+    }
+    if (open) {
+      // ---- open a round: lane l takes samples l, l + LP, ...
+      double theta = theta0;
+      for (int q = 0; q < l; ++q) theta += theta_res;
+      double ub[NP], umax = -1e300;
+      double sqx_l[NP], sqy_l[NP];
+      int kk[NP];
+      bool valid[NP];
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int j = l + LP * ps;
+        valid[ps] = (theta < theta0 + 2 * kPI) && (j < kMaxSlots);
+        n_emit += __popc(ballot_g(valid[ps]));  // theta increases with j: the valid samples are a prefix
+        ub[ps] = -1e300;
+        kk[ps] = 0;
+        sqx_l[ps] = 0.0; sqy_l[ps] = 0.0;
+        if (valid[ps]) {
+          const size_t s = (size_t)j * stride + ia;
+          const double qx = cx + 1.0 * r * cos(theta);
+          const double qy = cy + 1.0 * r * sin(theta);
+          sqx_l[ps] = qx; sqy_l[ps] = qy;
+          if constexpr (MODE != 1) {
+            // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
+            double d2min = 1e300;
+            int c0 = 0;
+            for (int c = 0; c < nch; ++c) {
+              const Chunk ch = chunks[c];
+              const double ex = qx - ch.cx, ey = qy - ch.cy;
+              const double d2 = ex * ex + ey * ey;
+              if (d2 < d2min) { d2min = d2; c0 = c; }
+            }
+            double u = 1e300;
+            const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
+            for (int k = c0 * kChunk; k < k1; ++k) u = dmin(u, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
+            ub[ps] = u;
+            gst<COH>(&gs.sq_ub[s], u);
+          }
+          gst<COH>(&gs.sqx[s], qx); gst<COH>(&gs.sqy[s], qy); gst<COH>(&gs.sqth[s], theta); gst<COH>(&gs.sq_sdf[s], kUnsolved);
+        }
+        if (ps + 1 < NP) {
+#pragma unroll
+          for (int q = 0; q < LP; ++q) theta += theta_res;
+        }
+      }
+      if constexpr (FULL) {
+        // Tightest bound layer 1 can give: the sample's own seed (the full pruned scan its solve would start
+        // with), found here by 8 cooperating lanes per sample -- LP / 8 samples at a time -- and handed to
+        // k_solve, which then skips its scan.  For shapes / trajectories where the nearest chunk is a poor
+        // guess (sdHorseshoe: 5.3 -> 2 solves per point) this is the difference between solving most samples
+        // and solving the one that matters.
+        constexpr int SG = LP / 8;
+        const int sg = l >> 3;
+        for (int p = 0; p * SG < n_emit; ++p) {
+          const int sidx = p * SG + sg;             // sample this 8-lane sub-group scans in this pass
+          const int slot = sidx / LP;               // uniform over the point's lanes (SG == 1 when NP > 1)
+          double sxs = sqx_l[0], sys = sqy_l[0];
+#pragma unroll
+          for (int ps = 1; ps < NP; ++ps)
+            if (slot == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
+          const double qx = __shfl(sxs, sidx % LP, LP), qy = __shfl(sys, sidx % LP, LP);
+          double bd = -1e300;
+          int bk = 0;
+          if (sidx < n_emit) {
+            bool cu;
+            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
+          }
+          // hand the result to the lane that owns the sample: sub-group (j % SG) scanned sample j in pass j / SG
+          const double rb = __shfl(bd, (l % SG) * 8, LP);
+          const int rk = __shfl(bk, (l % SG) * 8, LP);
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps)
+            if (valid[ps] && (l + LP * ps) / SG == p) { ub[ps] = rb; kk[ps] = rk; }
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+          if (valid[ps]) {
+            const size_t s = (size_t)(l + LP * ps) * stride + ia;
+            gst<COH>(&gs.sq_ub[s], ub[ps]);
+            gst<COH>(&gs.sq_k[s], kk[ps]);
+          }
+      }
+      if constexpr (MODE == 2) {
+        // Lazy scans: the cheap bounds single out the samples the cheap mode would solve (within band_delta of the
+        // best one); those get their own pruned table scan (8 lanes per sample, LP / 8 at a time) and only the best
+        // of THEM by the scanned bound are requested; the seeds go to k_solve (sq_k >= 0), unscanned samples keep
+        // their cheap bound (sq_k = -1: a supplementary solve scans itself).  Any selection is exact: closing the
+        // round requests whatever unsolved sample's bound still reaches the best solved value.
+        constexpr int SG = LP / 8;
+        const int sg = l >> 3;
+        double uc = -1e300;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) uc = fmax(uc, ub[ps]);
+        uc = fmax(uc, Grp<LP>::template xchg<0>(uc));
+        uc = fmax(uc, Grp<LP>::template xchg<1>(uc));
+        uc = fmax(uc, Grp<LP>::template xchg<2>(uc));
+        if constexpr (LP == 32) {
+          uc = fmax(uc, Grp<LP>::template xchg<3>(uc));
+          uc = fmax(uc, Grp<LP>::template xchg<4>(uc));
+        }
+        bool inband[NP], scanned[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) { inband[ps] = valid[ps] && ub[ps] >= uc - band_delta; scanned[ps] = false; kk[ps] = -1; }
+        double u2 = -1e300;   // best scanned bound so far
+        for (int rep = 0; rep < SVSDF_LAZY_REPS; ++rep) {
+          unsigned mp[NP];
+          int myrank[NP];
+          int nb = 0;
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) {
+            mp[ps] = ballot_g(inband[ps] && !scanned[ps]);
+            myrank[ps] = nb + __popc(mp[ps] & lt_mask);
+            nb += __popc(mp[ps]);
+          }
+          if (nb == 0) break;
+          for (int p = 0; p * SG < nb; ++p) {
+            const int r = p * SG + sg;          // rank (among the pending samples) this 8-lane sub-group scans
+            int rr = r, sps = 0, sl = 0;
+            bool found = false;
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const int c = __popc(mp[ps]);
+              if (!found && r < nb && rr < c) {
+                unsigned m = mp[ps];
+                for (int q = 0; q < rr; ++q) m &= m - 1u;
+                sl = __ffs(m) - 1;
+                sps = ps;
+                found = true;
+              } else if (!found) {
+                rr -= c;
+              }
+            }
+            double sxs = sqx_l[0], sys = sqy_l[0];
+#pragma unroll
+            for (int ps = 1; ps < NP; ++ps)
+              if (sps == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
+            const double qx = __shfl(sxs, sl, LP), qy = __shfl(sys, sl, LP);
+            double bd = -1e300;
+            int bk = 0;
+            if (found) {
+              bool cu;
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const bool mine = inband[ps] && !scanned[ps] && (myrank[ps] / SG == p);
+              const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
+              const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
+              if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
+            }
+          }
+          // extend the band to unscanned samples whose cheap bound still reaches the best scanned one
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) u2 = scanned[ps] ? fmax(u2, ub[ps]) : u2;
+          u2 = fmax(u2, Grp<LP>::template xchg<0>(u2));
+          u2 = fmax(u2, Grp<LP>::template xchg<1>(u2));
+          u2 = fmax(u2, Grp<LP>::template xchg<2>(u2));
+          if constexpr (LP == 32) {
+            u2 = fmax(u2, Grp<LP>::template xchg<3>(u2));
+            u2 = fmax(u2, Grp<LP>::template xchg<4>(u2));
+          }
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) inband[ps] = inband[ps] || (valid[ps] && !scanned[ps] && ub[ps] >= u2 - delta);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+          if (valid[ps]) {
+            const size_t s = (size_t)(l + LP * ps) * stride + ia;
+            gst<COH>(&gs.sq_ub[s], ub[ps]);
+            gst<COH>(&gs.sq_k[s], kk[ps]);
+            if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
+          }
+      }
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) umax = fmax(umax, ub[ps]);
+      umax = fmax(umax, Grp<LP>::template xchg<0>(umax));
+      umax = fmax(umax, Grp<LP>::template xchg<1>(umax));
+      umax = fmax(umax, Grp<LP>::template xchg<2>(umax));
+      if constexpr (LP == 32) {
+        umax = fmax(umax, Grp<LP>::template xchg<3>(umax));
+        umax = fmax(umax, Grp<LP>::template xchg<4>(umax));
+      }
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        list_me[ps] = valid[ps] && ub[ps] >= umax - delta;
+        mlist[ps] = ballot_g(list_me[ps]);
+      }
+      push_next = true;
+      if (l == 0) { gst<COH>(&gs.nsamp[ia], n_emit); gst<COH>(&gs.phase[ia], (int)kPhaseEval); }
+    }
+  }
+
 // LP lanes per point (8 or 32): the early rounds have 2 and 6 samples, the later ones 18-21; a
 // point with more samples than lanes is handled in ceil(n / LP) passes.
 #ifndef SVSDF_ROUND_BLOCK
@@ -941,7 +1261,6 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx,
         double *__restrict__ res_gy, BatchCtl *__restrict__ ctl) {
   static_assert(LP == 8 || LP == 32, "lanes per point");
-  constexpr bool FULL = MODE == 1;
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   extern __shared__ double round_lds[];
   __shared__ int s_cnt[3][kRoundBlock / LP];   // per point slot: solves, next-list entries, samples
@@ -968,285 +1287,31 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   const int hw = (int)(threadIdx.x / LP);
   unsigned n_scan = 0;   // table evaluations of the cooperative seed scans (FULL)
   const unsigned lt_mask = (1u << l) - 1u;
-  auto ballot_g = [&](bool p) -> unsigned {   // bit i <=> lane i of this point's lane group
-    const unsigned long long m = __ballot(p);
-    const int base = (int)(threadIdx.x & 63) & ~(LP - 1);
-    return (unsigned)((m >> base) & ((LP == 32) ? 0xffffffffull : 0xffull));
-  };
   // block-uniform trip count; lane groups without a point still take part in the barriers
   for (int e0 = (int)blockIdx.x * ppb; e0 < n_act; e0 += (int)gridDim.x * ppb) {
     const int e = e0 + hw;
     const bool active = e < n_act;
-    int a = 0, i = 0, n_emit = 0, n_list = 0;
+    int a = 0, n_emit = 0, n_list = 0;
     size_t ia = 0;
-    bool push_next = false, open = false;
+    bool push_next = false;
     bool list_me[NP];
     unsigned mlist[NP];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) { list_me[ps] = false; mlist[ps] = 0u; }
-    double cx = 0.0, cy = 0.0, r = 0.0, theta0 = 0.0, theta_res = 0.0;
+    RoundOut<NP> ro;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) { ro.list_me[ps] = false; ro.mlist[ps] = 0u; }
+    ro.n_emit = 0; ro.push_next = false; ro.finished = false;
     if (active) {
       a = cur[e];
-      ia = (size_t)start + a;
-      i = gs.pt[ia];
-      cx = px_[i]; cy = py_[i];
-      r = gs.r[ia]; theta0 = gs.theta0[ia]; theta_res = gs.theta_res[ia];
-      open = gs.phase[ia] == kPhaseNew;
-      if (!open) {
-        // ---- close the round: max over the solved samples, first index wins ties (strict >)
-        const int n = gs.nsamp[ia];
-        double g_mine[NP];
-        double g = kUnsolved;
-        int idx = 0x7fffffff;
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-          const int j = l + LP * ps;
-          g_mine[ps] = (j < n) ? gs.sq_sdf[(size_t)j * stride + ia] : kUnsolved;
-          if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
-        }
-        {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
-          auto step = [&](double og, int oi) { if (og > g || (og == g && oi < idx)) { g = og; idx = oi; } };
-          step(Grp<LP>::template xchg<0>(g), Grp<LP>::template xchg<0>(idx));
-          step(Grp<LP>::template xchg<1>(g), Grp<LP>::template xchg<1>(idx));
-          step(Grp<LP>::template xchg<2>(g), Grp<LP>::template xchg<2>(idx));
-          if constexpr (LP == 32) {
-            step(Grp<LP>::template xchg<3>(g), Grp<LP>::template xchg<3>(idx));
-            step(Grp<LP>::template xchg<4>(g), Grp<LP>::template xchg<4>(idx));
-          }
-        }
-        double max_g = -100000, real_t = res_t[i], star_th = 0.0;
-        if (g > max_g) {
-          const size_t sb = (size_t)idx * stride + ia;
-          max_g = g; real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
-        }
-        // unsolved samples that could still reach max_g -> supplementary solves
-        bool any = false;
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-          const int j = l + LP * ps;
-          list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gs.sq_ub[(size_t)j * stride + ia] >= max_g;
-          mlist[ps] = ballot_g(list_me[ps]);
-          any = any || (mlist[ps] != 0u);
-        }
-        if (any) {
-          push_next = true;
-          if (l == 0) gs.phase[ia] = kPhaseSupp;
-        } else {
-          const double r_star = r - max_g;
-          const int iter = gs.iter[ia];
-          if (iter > 8 || fabs(max_g) < 0.1) {
-            if (l == 0) {
-              const double corx = cx + 1.0 * r_star * cos(star_th);
-              const double cory = cy + 1.0 * r_star * sin(star_th);
-              double gx = corx - cx, gy = cory - cy;
-              const double z = gx * gx + gy * gy;
-              if (z > 0.0) { const double nn = sqrt(z); gx = gx / nn; gy = gy / nn; }
-              res_sdf[i] = -r_star; res_t[i] = real_t; res_gx[i] = gx; res_gy[i] = gy;
-            }
-          } else {
-            // expandSet(2, theta*)
-            theta_res = theta_res / (2 + 1);
-            theta_res = dmax(0.3, theta_res);
-            r = r_star;
-            theta0 = star_th;
-            if (l == 0) {
-              gs.r[ia] = r; gs.theta_res[ia] = theta_res; gs.theta0[ia] = theta0; gs.iter[ia] = iter + 1;
-              res_t[i] = real_t;
-            }
-            open = true;
-          }
-        }
-      }
-      if (open) {
-        // ---- open a round: lane l takes samples l, l + LP, ...
-        double theta = theta0;
-        for (int q = 0; q < l; ++q) theta += theta_res;
-        double ub[NP], umax = -1e300;
-        double sqx_l[NP], sqy_l[NP];
-        int kk[NP];
-        bool valid[NP];
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-          const int j = l + LP * ps;
-          valid[ps] = (theta < theta0 + 2 * kPI) && (j < kMaxSlots);
-          n_emit += __popc(ballot_g(valid[ps]));  // theta increases with j: the valid samples are a prefix
-          ub[ps] = -1e300;
-          kk[ps] = 0;
-          sqx_l[ps] = 0.0; sqy_l[ps] = 0.0;
-          if (valid[ps]) {
-            const size_t s = (size_t)j * stride + ia;
-            const double qx = cx + 1.0 * r * cos(theta);
-            const double qy = cy + 1.0 * r * sin(theta);
-            sqx_l[ps] = qx; sqy_l[ps] = qy;
-            if constexpr (MODE != 1) {
-              // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
-              double d2min = 1e300;
-              int c0 = 0;
-              for (int c = 0; c < nch; ++c) {
-                const Chunk ch = chunks[c];
-                const double ex = qx - ch.cx, ey = qy - ch.cy;
-                const double d2 = ex * ex + ey * ey;
-                if (d2 < d2min) { d2min = d2; c0 = c; }
-              }
-              double u = 1e300;
-              const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
-              for (int k = c0 * kChunk; k < k1; ++k) u = dmin(u, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
-              ub[ps] = u;
-              gs.sq_ub[s] = u;
-            }
-            gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_sdf[s] = kUnsolved;
-          }
-          if (ps + 1 < NP) {
-#pragma unroll
-            for (int q = 0; q < LP; ++q) theta += theta_res;
-          }
-        }
-        if constexpr (FULL) {
-          // Tightest bound layer 1 can give: the sample's own seed (the full pruned scan its solve would start
-          // with), found here by 8 cooperating lanes per sample -- LP / 8 samples at a time -- and handed to
-          // k_solve, which then skips its scan.  For shapes / trajectories where the nearest chunk is a poor
-          // guess (sdHorseshoe: 5.3 -> 2 solves per point) this is the difference between solving most samples
-          // and solving the one that matters.
-          constexpr int SG = LP / 8;
-          const int sg = l >> 3;
-          for (int p = 0; p * SG < n_emit; ++p) {
-            const int sidx = p * SG + sg;             // sample this 8-lane sub-group scans in this pass
-            const int slot = sidx / LP;               // uniform over the point's lanes (SG == 1 when NP > 1)
-            double sxs = sqx_l[0], sys = sqy_l[0];
-#pragma unroll
-            for (int ps = 1; ps < NP; ++ps)
-              if (slot == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
-            const double qx = __shfl(sxs, sidx % LP, LP), qy = __shfl(sys, sidx % LP, LP);
-            double bd = -1e300;
-            int bk = 0;
-            if (sidx < n_emit) {
-              bool cu;
-              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
-            }
-            // hand the result to the lane that owns the sample: sub-group (j % SG) scanned sample j in pass j / SG
-            const double rb = __shfl(bd, (l % SG) * 8, LP);
-            const int rk = __shfl(bk, (l % SG) * 8, LP);
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps)
-              if (valid[ps] && (l + LP * ps) / SG == p) { ub[ps] = rb; kk[ps] = rk; }
-          }
-#pragma unroll
-          for (int ps = 0; ps < NP; ++ps)
-            if (valid[ps]) {
-              const size_t s = (size_t)(l + LP * ps) * stride + ia;
-              gs.sq_ub[s] = ub[ps];
-              gs.sq_k[s] = kk[ps];
-            }
-        }
-        if constexpr (MODE == 2) {
-          // Lazy scans: the cheap bounds single out the samples the cheap mode would solve (within band_delta of the
-          // best one); those get their own pruned table scan (8 lanes per sample, LP / 8 at a time) and only the best
-          // of THEM by the scanned bound are requested; the seeds go to k_solve (sq_k >= 0), unscanned samples keep
-          // their cheap bound (sq_k = -1: a supplementary solve scans itself).  Any selection is exact: closing the
-          // round requests whatever unsolved sample's bound still reaches the best solved value.
-          constexpr int SG = LP / 8;
-          const int sg = l >> 3;
-          double uc = -1e300;
-#pragma unroll
-          for (int ps = 0; ps < NP; ++ps) uc = fmax(uc, ub[ps]);
-          uc = fmax(uc, Grp<LP>::template xchg<0>(uc));
-          uc = fmax(uc, Grp<LP>::template xchg<1>(uc));
-          uc = fmax(uc, Grp<LP>::template xchg<2>(uc));
-          if constexpr (LP == 32) {
-            uc = fmax(uc, Grp<LP>::template xchg<3>(uc));
-            uc = fmax(uc, Grp<LP>::template xchg<4>(uc));
-          }
-          bool inband[NP], scanned[NP];
-#pragma unroll
-          for (int ps = 0; ps < NP; ++ps) { inband[ps] = valid[ps] && ub[ps] >= uc - band_delta; scanned[ps] = false; kk[ps] = -1; }
-          double u2 = -1e300;   // best scanned bound so far
-          for (int rep = 0; rep < SVSDF_LAZY_REPS; ++rep) {
-            unsigned mp[NP];
-            int myrank[NP];
-            int nb = 0;
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-              mp[ps] = ballot_g(inband[ps] && !scanned[ps]);
-              myrank[ps] = nb + __popc(mp[ps] & lt_mask);
-              nb += __popc(mp[ps]);
-            }
-            if (nb == 0) break;
-            for (int p = 0; p * SG < nb; ++p) {
-              const int r = p * SG + sg;          // rank (among the pending samples) this 8-lane sub-group scans
-              int rr = r, sps = 0, sl = 0;
-              bool found = false;
-#pragma unroll
-              for (int ps = 0; ps < NP; ++ps) {
-                const int c = __popc(mp[ps]);
-                if (!found && r < nb && rr < c) {
-                  unsigned m = mp[ps];
-                  for (int q = 0; q < rr; ++q) m &= m - 1u;
-                  sl = __ffs(m) - 1;
-                  sps = ps;
-                  found = true;
-                } else if (!found) {
-                  rr -= c;
-                }
-              }
-              double sxs = sqx_l[0], sys = sqy_l[0];
-#pragma unroll
-              for (int ps = 1; ps < NP; ++ps)
-                if (sps == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
-              const double qx = __shfl(sxs, sl, LP), qy = __shfl(sys, sl, LP);
-              double bd = -1e300;
-              int bk = 0;
-              if (found) {
-                bool cu;
-                scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
-              }
-#pragma unroll
-              for (int ps = 0; ps < NP; ++ps) {
-                const bool mine = inband[ps] && !scanned[ps] && (myrank[ps] / SG == p);
-                const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
-                const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
-                if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
-              }
-            }
-            // extend the band to unscanned samples whose cheap bound still reaches the best scanned one
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) u2 = scanned[ps] ? fmax(u2, ub[ps]) : u2;
-            u2 = fmax(u2, Grp<LP>::template xchg<0>(u2));
-            u2 = fmax(u2, Grp<LP>::template xchg<1>(u2));
-            u2 = fmax(u2, Grp<LP>::template xchg<2>(u2));
-            if constexpr (LP == 32) {
-              u2 = fmax(u2, Grp<LP>::template xchg<3>(u2));
-              u2 = fmax(u2, Grp<LP>::template xchg<4>(u2));
-            }
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) inband[ps] = inband[ps] || (valid[ps] && !scanned[ps] && ub[ps] >= u2 - delta);
-          }
-#pragma unroll
-          for (int ps = 0; ps < NP; ++ps)
-            if (valid[ps]) {
-              const size_t s = (size_t)(l + LP * ps) * stride + ia;
-              gs.sq_ub[s] = ub[ps];
-              gs.sq_k[s] = kk[ps];
-              if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
-            }
-        }
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) umax = fmax(umax, ub[ps]);
-        umax = fmax(umax, Grp<LP>::template xchg<0>(umax));
-        umax = fmax(umax, Grp<LP>::template xchg<1>(umax));
-        umax = fmax(umax, Grp<LP>::template xchg<2>(umax));
-        if constexpr (LP == 32) {
-          umax = fmax(umax, Grp<LP>::template xchg<3>(umax));
-          umax = fmax(umax, Grp<LP>::template xchg<4>(umax));
-        }
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-          list_me[ps] = valid[ps] && ub[ps] >= umax - delta;
-          mlist[ps] = ballot_g(list_me[ps]);
-        }
-        push_next = true;
-        if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = kPhaseEval; }
-      }
+      round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, delta, band_delta, res_sdf,
+                                   res_t, res_gx, res_gy, n_scan, ro);
     }
+    ia = (size_t)start + a;
+    push_next = ro.push_next;
+    n_emit = ro.n_emit;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) { list_me[ps] = ro.list_me[ps]; mlist[ps] = ro.mlist[ps]; }
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) n_list += __popc(mlist[ps]);
     // ---- one set of list atomics per block iteration
@@ -1275,7 +1340,10 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         pos += __popc(mlist[ps]);
       }
     }
-    if (push_next && l == 0) nxt[s_base[1][hw]] = a;
+    if (push_next && l == 0) {
+      nxt[s_base[1][hw]] = a;
+      gs.pending[ia] = n_list;   // solves outstanding for this point (read by the persistent GSIP kernel only)
+    }
     __syncthreads();
   }
   if constexpr (MODE != 0) {
@@ -1283,6 +1351,304 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tc += __shfl_xor(tc, m, 64);
     if ((threadIdx.x & 63) == 0 && tc) { atomicAdd(&ctl->stat_scan, tc); atomicAdd(&ctl->stat_evals, tc); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gsip: the whole GSIP loop of a batch in ONE persistent launch (experimental, env SVSDF_PERSISTENT=1).
+//
+// After k_round(0) opened round 1 of every interior point, the chain  k_solve(i) -> k_round(i+1)  (~10 dependent launch
+// pairs, each with a ramp-up and a tail, every point waiting for the slowest one of its iteration) is replaced by task
+// queues in device memory served by persistent waves:
+//   SOLVE task (payload = sample slot >= 0): layer-1 scan unless seeded, layers 2-4, descent (descend_from_seed); the
+//                solve that brings its point's `pending` counter to zero queues the point's ROUND task
+//   ROUND task (payload = -2 - interior index): 32 lanes, round_point -- close / supplementary / finish / open -- and
+//                the SOLVE tasks it requests (pending = their number)
+// so a point advances as soon as ITS solves are done.
+//
+// Queues.  One address takes ~80 M atomics per second on this part (tools/experiments/coh_latency.hip: 37 us per
+// returning atomicAdd when 3072 waves share one counter, 0.4 us when they do not), and an evaluation at 1 M points moves
+// ~3 M tasks: a single queue is bound by its two cursors.  So there are nq (<= 256) queue shards, each with its own
+// cursors in its own cache line and its own ring; a wave consumes from its home shard (wave id mod nq: ~12 waves per
+// shard) and pushes what it produces to the shards in rotation.  Within a shard: positions 0, 1, 2, ... handed out by two
+// fetch-adds -- producers reserve at `reserve`, consumers take tickets at `head` (tickets may run ahead of the
+// reservations: an idle wave then waits on its own positions, no shared word is polled).  Position p lives in ring slot
+// p % Qs as (p + 1) << 32 | payload: the tag says the entry is the one the ticket is for, the consumer zeroes the slot when
+// it takes the entry, a producer only writes a zero slot (the rings hold twice the tasks that can be outstanding plus a
+// slack, so it never waits in practice).  k_round(0)'s solve list is dealt out statically, 16 entries per wave and turn.
+// A ticket is as many positions as the shard has unclaimed reservations -- 16, 8, 4 (SOLVE: 4, 8, 16 lanes per task) --
+// and 2 when there are fewer (32 lanes per task, the chain's late-iteration width: the critical path of the tail); any
+// width gives the same bits.  Everything one wave hands to another (possibly on a different XCD) goes through coherent
+// accesses (gld / gst), ordered by the wave's own completion counters: no cache-wide fences (94 us each under load).
+// End: waves count the points they finished and add them to ctl->q_done when they run dry; the wave that completes the
+// count raises every shard's stop word.  Same arithmetic per point as the chain (round_point, descend_from_seed): same
+// results.  A spin cap raises q_error and the host reruns the evaluation through the launch chain.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned q_load(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long q_peek(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// publish payload at position pos (the data it refers to is already written and complete)
+__device__ __forceinline__ bool q_put(unsigned long long *ring, unsigned Q, unsigned pos, int payload) {
+  unsigned long long *slot = ring + (pos % Q);
+  for (int spin = 0; q_peek(slot) != 0ull; ++spin) {   // previous lap not taken yet: the ring is sized so that this never waits
+    if (spin > (1 << 20)) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_store(slot, ((unsigned long long)(pos + 1u) << 32) | (unsigned long long)(unsigned)payload, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// SOLVE tasks of a ticket by G lanes each (lane group g <-> ticket entry g): solve, store, count down the point's
+// `pending`; returns (leader lane of the group) whether this was the point's last solve and the point's index
+template <int SHAPE, int MODE, int G>
+__device__ __forceinline__ void gsip_solve(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
+                                           const Pose *pose, const Chunk *chunks, int K, int nch, const GsipState &gs,
+                                           size_t stride, int start, bool live, int payload, bool &last, int &a_done,
+                                           unsigned &n_eval, unsigned &n_scan, unsigned &n_solved) {
+  last = false;
+  a_done = 0;
+  if (!live) return;
+  const size_t slot = (size_t)payload;
+  const double qx = gld<true>(&gs.sqx[slot]), qy = gld<true>(&gs.sqy[slot]);
+  double best_d = 1e9, x = 0.0, fx = 0.0;
+  int best_k = -1;
+  if constexpr (MODE != 0) { best_k = gld<true>(&gs.sq_k[slot]); best_d = gld<true>(&gs.sq_ub[slot]); }
+  if (best_k < 0) {
+    bool culled;
+    scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), best_d, best_k,
+                          culled, n_scan);
+  }
+  descend_from_seed<SHAPE, G, 1>(tr, tk, sp, qx, qy, best_k, best_d, x, fx, n_eval);
+  if (Grp<G>::li() == 0) {
+    gst<true>(&gs.sq_sdf[slot], fx);
+    gst<true>(&gs.sq_t[slot], x);
+    ++n_solved;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the solved value is out before the counter moves
+    const size_t ia = slot % stride;
+    last = atomicSub(&gs.pending[ia], 1) == 1;
+    a_done = (int)(ia - (size_t)start);
+  }
+}
+
+#ifndef SVSDF_GSIP_WAVES
+#define SVSDF_GSIP_WAVES 3   // waves per SIMD the register allocation aims at (k_solve's 146 VGPRs give 3 as well)
+#endif
+template <int SHAPE, int MODE>
+__global__ void __launch_bounds__(kBlock, SVSDF_GSIP_WAVES)
+k_gsip(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
+       const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_, const double *__restrict__ py_,
+       GsipState gs, size_t stride, double sel_delta, double sel_band, int all_round, int grace, int nq,
+       double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
+       BatchCtl *__restrict__ ctl) {
+  constexpr int LP = 32;
+  extern __shared__ double gsip_lds[];
+  const int n_int = ctl->n_active[0];   // interior points of this batch
+  if (n_int <= 0) return;
+  const int K = trg->K;
+  const int nch = (K + kChunk - 1) / kChunk;
+  Pose *pose = reinterpret_cast<Pose *>(gsip_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(gsip_lds + 4 * (size_t)K);
+  {
+    const double *src = reinterpret_cast<const double *>(pose_g);
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) gsip_lds[i] = src[i];
+    const double *srcc = reinterpret_cast<const double *>(chunks_g);
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) gsip_lds[4 * (size_t)K + i] = srcc[i];
+  }
+  const TrajL tr = stage_traj(trg, gsip_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
+  const int start = ctl->start, count = ctl->count;
+  const unsigned n0 = (unsigned)ctl->n_solve[0];          // k_round(0)'s solve list
+  const int *list0 = gs.solve + (size_t)start * kMaxSlots;
+  const unsigned Qs = gsip_shard_slots(count, nq);        // ring slots per shard
+  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+  const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned home_s = wave_id & (unsigned)(nq - 1);
+  QShard *home = gs.qsh + home_s;
+  unsigned long long *home_ring = gs.q + (size_t)home_s * Qs;
+  unsigned rr = wave_id * 40503u;                         // rotation of the shards this wave pushes to
+  unsigned c0 = wave_id;                                  // next 16-entry chunk of the initial list
+  const int lane = (int)(threadIdx.x & 63);
+  const int hw = lane / LP, l = lane & (LP - 1);
+  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_emit_tot = 0;
+  unsigned my_done = 0;                                   // lane 0: points this wave finished since its last flush
+  bool quit = false;
+  // an error: record it and stop every wave (the host falls back to the launch chain)
+  auto raise = [&](int code) {
+    atomicExch(&ctl->q_error, code);
+    for (int s = 0; s < nq; ++s) gst<true>(&gs.qsh[s].stop, 1u);
+  };
+  while (!quit) {
+    // ---------------- the next entries: a chunk of the initial list, else a ticket of the home shard -- as many
+    // positions as the shard has reserved tasks nobody holds a ticket for (16, 8, 4; their entries are on their way),
+    // 2 when there are fewer (the shard's waves are not all busy: the widest lane groups, the shortest chain)
+    unsigned t0 = 0;
+    int tn = 16;
+    const bool from_list = c0 * 16u < n0;
+    if (from_list) {
+      t0 = c0 * 16u;
+      c0 += n_waves;
+    } else {
+      if (lane == 0) {
+        const int backlog = (int)(q_load(&home->reserve) - q_load(&home->head));
+        tn = (backlog >= 16) ? 16 : (backlog >= 8) ? 8 : (backlog >= 4) ? 4 : 2;
+        t0 = atomicAdd(&home->head, (unsigned)tn);
+      }
+      tn = __builtin_amdgcn_readfirstlane(tn);
+      t0 = __builtin_amdgcn_readfirstlane(t0);
+    }
+    const int gl = 64 / tn;                   // lanes per entry
+    const int e = lane / gl;                  // this lane's entry
+    const bool leader = (lane % gl) == 0;
+    const unsigned pos = t0 + (unsigned)e;
+    unsigned todo = (1u << tn) - 1u;          // entries not processed yet (wave-uniform)
+    if (from_list && t0 + 16u > n0) todo = (1u << (n0 - t0)) - 1u;
+    int polls = 0, waited = 0;
+    bool have = false;                        // leader lanes: entry taken from the ring, not processed yet
+    int payload = 0;
+    while (todo) {
+      // ---------------- poll the entries' slots
+      if (leader && ((todo >> e) & 1u) && !have) {
+        if (from_list) {
+          have = true;
+          payload = list0[pos];
+        } else {
+          unsigned long long *slot = home_ring + (pos % Qs);
+          const unsigned long long v = q_peek(slot);
+          if ((unsigned)(v >> 32) == pos + 1u) {
+            have = true;
+            payload = (int)(unsigned)(v & 0xffffffffull);
+            __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // taken
+          }
+        }
+      }
+      const unsigned long long hm = __ballot(have);
+      // a ticket of 4+ positions was sized by reservations: its entries arrive within microseconds of each other, and a
+      // pass costs the same for 3 entries as for 16 -- wait (a bounded while) for the ticket to be complete
+      if (hm != 0ull && tn > 2 && waited < grace && (unsigned)__popcll(hm) < (unsigned)__popc(todo)) {
+        ++waited;
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      if (hm == 0ull) {
+        ++polls;
+        int stop = 0;
+        if (lane == 0) {
+          if (polls == 1 && my_done > 0u) {   // run dry: hand in the finished points; the last one ends the launch
+            const unsigned before = atomicAdd(&ctl->q_done, my_done);
+            if (before + my_done >= (unsigned)n_int) stop = 2;
+            my_done = 0u;
+          }
+          if (!stop && q_load(&home->stop) != 0u) stop = 1;
+        }
+        stop = __builtin_amdgcn_readfirstlane(stop);
+        if (stop == 2)
+          for (int s = lane; s < nq; s += 64) gst<true>(&gs.qsh[s].stop, 1u);
+        if (stop) { quit = true; break; }
+        if (polls > (1 << 21)) {   // ~ seconds without a task and without the end: give up loudly
+          if (lane == 0) raise(3);
+          quit = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      polls = 0;
+      unsigned got = 0u;   // entries taken in this pass
+      for (unsigned long long m = hm; m; m &= m - 1ull) got |= 1u << ((__ffsll((long long)m) - 1) / gl);
+      todo &= ~got;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the entries' data is read after the entries (coherent loads)
+      // every lane of an entry's group learns its payload
+      const int pl = __shfl(payload, e * gl, 64);
+      const bool mine = (got >> e) & 1u;
+      have = false;
+      // ---------------- SOLVE entries, one lane group each
+      bool last = false;
+      int a_done = 0;
+      if (tn == 16)
+        gsip_solve<SHAPE, MODE, 4>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
+                                   n_eval, n_scan, n_solved);
+      else if (tn == 8)
+        gsip_solve<SHAPE, MODE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
+                                   n_eval, n_scan, n_solved);
+      else if (tn == 4)
+        gsip_solve<SHAPE, MODE, 16>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
+                                    n_eval, n_scan, n_solved);
+      else
+        gsip_solve<SHAPE, MODE, 32>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
+                                    n_eval, n_scan, n_solved);
+      {  // the points whose last solve this was: their ROUND tasks, one reservation per wave
+        const unsigned long long lm = __ballot(last);
+        if (lm) {
+          const int cnt = __popcll(lm);
+          const unsigned ts = (rr++) & (unsigned)(nq - 1);
+          unsigned rp = 0;
+          if (lane == 0) rp = atomicAdd(&gs.qsh[ts].reserve, (unsigned)cnt);
+          rp = __builtin_amdgcn_readfirstlane(rp);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (last && !q_put(gs.q + (size_t)ts * Qs, Qs, rp + (unsigned)__popcll(lm & ((1ull << lane) - 1ull)), -2 - a_done))
+            raise(2);
+        }
+      }
+      // ---------------- ROUND entries, two at a time (32 lanes each)
+      unsigned rmask = 0u;
+      {
+        const unsigned long long rm = __ballot(leader && mine && pl < 0);
+        for (unsigned long long m = rm; m; m &= m - 1ull) rmask |= 1u << ((__ffsll((long long)m) - 1) / gl);
+      }
+      while (rmask) {
+        const int e0 = __ffs(rmask) - 1;
+        rmask &= rmask - 1u;
+        int e1 = -1;
+        if (rmask) { e1 = __ffs(rmask) - 1; rmask &= rmask - 1u; }
+        const int my_e = hw == 0 ? e0 : e1;
+        const bool active = my_e >= 0;
+        const int pv = __shfl(payload, (active ? my_e : 0) * gl, 64);   // from the entry's leader lane (all lanes take part)
+        const int a = active ? -2 - pv : 0;
+        const size_t ia = (size_t)start + a;
+        RoundOut<1> ro;
+        ro.list_me[0] = false; ro.mlist[0] = 0u; ro.n_emit = 0; ro.push_next = false; ro.finished = false;
+        if (active) {
+          // late rounds request every sample (no supplementary hand-over); any selection gives the same result
+          const bool all = gld<true>(&gs.iter[ia]) >= all_round;
+          round_point<SHAPE, LP, MODE, true>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, all ? 1e300 : sel_delta,
+                                             all ? 1e300 : sel_band, res_sdf, res_t, res_gx, res_gy, n_scan, ro);
+        }
+        const int n_list = __popc(ro.mlist[0]);   // uniform over the point's lanes
+        if (active && l == 0) {
+          n_emit_tot += (unsigned)ro.n_emit;
+          if (ro.push_next && n_list == 0) raise(4);   // cannot happen: a round has >= 1 sample
+          if (n_list > 0) gst<true>(&gs.pending[ia], n_list);
+        }
+        // the wave's SOLVE requests: one reservation, the two points' entries one after the other
+        const int n_other = __shfl(n_list, lane ^ LP, 64);
+        const int n_wave = n_list + n_other;
+        if (n_wave > 0) {
+          const unsigned ts = (rr++) & (unsigned)(nq - 1);
+          unsigned sp0 = 0;
+          if (lane == 0) sp0 = atomicAdd(&gs.qsh[ts].reserve, (unsigned)n_wave);
+          sp0 = __builtin_amdgcn_readfirstlane(sp0);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // samples, bounds, point state, pending: written through
+          if (ro.list_me[0]) {
+            const unsigned at = sp0 + (unsigned)((hw == 0 ? 0 : n_other) + __popc(ro.mlist[0] & ((1u << l) - 1u)));
+            if (!q_put(gs.q + (size_t)ts * Qs, Qs, at, (int)((size_t)l * stride + ia))) raise(2);
+          }
+        }
+        const unsigned long long fin = __ballot(active && l == 0 && ro.finished);
+        if (lane == 0) my_done += (unsigned)__popcll(fin);
+      }
+    }
+  }
+  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tm = n_emit_tot;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tm += __shfl_xor(tm, m, 64);
+  }
+  if (lane == 0 && (te || tm)) {
+    atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); atomicAdd(&ctl->stat_scan, tc);
+    if (tm) atomicAdd(&ctl->n_seed[1], (int)tm);
   }
 }
 
@@ -1306,6 +1672,13 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
 }
 
 #ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_api.hip
+// queue cursors of a batch before its k_gsip launch
+__global__ void k_gsip_init(BatchCtl *__restrict__ ctl, QShard *__restrict__ shards) {
+  if (threadIdx.x == 0) { ctl->q_done = 0u; ctl->q_error = 0; }
+  QShard z{};
+  for (int s = threadIdx.x; s < kMaxShards; s += blockDim.x) shards[s] = z;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
@@ -1448,6 +1821,9 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
       for (int b = 0; b < nbatch; ++b) ns += (unsigned long long)ctl[b].n_solve[i];
       stats_out[9 + i] = ns;
     }
+    unsigned long long qe = 0;   // persistent GSIP kernel: non-zero = it gave up, the host reruns through the chain
+    for (int b = 0; b < nbatch; ++b) qe += (unsigned long long)(ctl[b].q_error != 0 ? ctl[b].q_error : 0);
+    stats_out[9 + kMaxIter] = qe;
   }
 }
 

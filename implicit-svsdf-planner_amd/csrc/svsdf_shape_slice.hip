@@ -1,9 +1,11 @@
 // svsdf_shape_slice.hip -- one slice of the shape-templated kernels (compile with -DSVSDF_SLICE=k, k = 0 .. 3).
 //
-// Slice k instantiates k_solve / k_round / k_classify / k_rbound / k_subsw / k_shape_kernels for the shapes with
+// Slice k instantiates k_solve / k_round / k_gsip / k_classify / k_rbound / k_subsw / k_shape_kernels for the shapes with
 // id % 4 == k and exports the launchers svsdf_api.hip dispatches to (svsdf_launch.hpp).  Splitting the ~250 kernel
 // instantiations over four translation units lets the build run in parallel (one TU took 140 s).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "svsdf_launch.hpp"
 
@@ -65,6 +67,33 @@ bool round_s(int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const 
       if (mode == 2) ROUND(32, 2); else if (mode == 1) ROUND(32, 1); else ROUND(32, 0);
     }
 #undef ROUND
+    return true;
+  }
+}
+
+template <int S>
+bool gsip_s(int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a) {
+  if constexpr (!shape_enabled<S>()) {
+    return false;
+  } else {
+#define GSIP(MODE)                                                                                                  \
+  do {                                                                                                              \
+    if (*a.blocks_per_cu <= 0) {                                                                                    \
+      int nb = 0;                                                                                                   \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsip<S, MODE>, (int)block, lds) != hipSuccess || nb < 1) \
+        return false;                                                                                               \
+      *a.blocks_per_cu = nb;                                                                                        \
+    }                                                                                                               \
+    const unsigned g = std::min(grid, (unsigned)(*a.blocks_per_cu * a.n_cu));                                       \
+    const unsigned waves = g * (block / 64);                                                                        \
+    int nq = 1;                                                                                                     \
+    while (nq * 2 <= kMaxShards && (unsigned)(nq * 2) * 8u <= waves) nq *= 2;   /* >= 8 waves per shard */           \
+    hipLaunchKernelGGL((k_gsip<S, MODE>), dim3(g), dim3(block), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp, a.px, \
+                       a.py, a.gs, a.stride, a.sel_delta, a.sel_band, a.all_round, a.grace, nq, a.res_sdf,     \
+                       a.res_t, a.res_gx, a.res_gy, a.ctl);                                                          \
+  } while (0)
+    if (mode == 2) GSIP(2); else if (mode == 1) GSIP(1); else GSIP(0);
+#undef GSIP
     return true;
   }
 }
@@ -136,6 +165,11 @@ bool SLICE_FN(launch_k_round)(int shape, int lp, int mode, unsigned grid, size_t
 }
 bool SLICE_FN(launch_k_classify)(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a) {
 #define CALL(S) classify_s<S>(grid, lds, st, a)
+  SLICE_SWITCH(CALL)
+#undef CALL
+}
+bool SLICE_FN(launch_k_gsip)(int shape, int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a) {
+#define CALL(S) gsip_s<S>(mode, grid, block, lds, st, a)
   SLICE_SWITCH(CALL)
 #undef CALL
 }
