@@ -127,6 +127,7 @@ struct svsdf_ctx {
   long long gsip_key[3] = {0, 0, -1};
   int n_cu = 256;
   int gsip_grace = 32;      // polls a wave waits for the rest of a reserved ticket once its first entry is there
+  int gsip_from = 0;         // SVSDF_PERSISTENT_FROM: GSIP iterations that still run as launches before k_gsip takes over
   int gsip_error = 0;        // k_gsip gave up (queue overflow / poll cap): the evaluation is rerun through the chain
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
@@ -345,8 +346,8 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   (void)launch_k_round(ctx->cfg.shape_id, lp, mode, grid, lds, st, a);
 }
 
-// The whole GSIP loop of batch b in one persistent launch (k_gsip), after k_round(0) opened every point's first round.
-void launch_gsip(svsdf_ctx *ctx, hipStream_t st, int b) {
+// The GSIP loop of batch b from iteration it0 on in one persistent launch (k_gsip), after k_round(it0).
+void launch_gsip(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
   const bool scans = mode != 0;
   const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
@@ -369,7 +370,7 @@ void launch_gsip(svsdf_ctx *ctx, hipStream_t st, int b) {
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   const GsipLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, gsb, ctx->P, sel,
-                     ctx->select_delta, all_it, ctx->gsip_grace, ctx->n_cu, &ctx->gsip_blocks_per_cu, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
+                     ctx->select_delta, all_it, ctx->gsip_grace, it0, std::max(1, ctx->n_cu / ctx->nbatch), &ctx->gsip_blocks_per_cu, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
   (void)launch_k_gsip(ctx->cfg.shape_id, mode, grid, (unsigned)blk, lds, st, a);
   if (ctx->profile) {
     e1 = next_event(ctx);
@@ -573,10 +574,13 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0, cull_thresh);
     launch_classify(ctx, st, b);
     launch_round(ctx, st, b, 0);
-    if (ctx->persistent) launch_gsip(ctx, st, b);
   }
   if (ctx->persistent) {
-    ctx->it_done = 1;   // k_finish: n_solve[1] stays zero, nothing pending
+    // the first gsip_from iterations as launches (their solve lists fill the chip), the rest in one persistent launch
+    const int it0 = std::max(0, std::min(ctx->gsip_from, (int)kMaxIter - 1));
+    for (int it = 0; it < it0; ++it) enqueue_solve_round(ctx, it);
+    for (int b = 0; b < ctx->nbatch; ++b) launch_gsip(ctx, ctx->bstream[b], b, it0);
+    ctx->it_done = it0 + 1;   // k_finish: n_solve[it0 + 1] stays zero, nothing pending
   } else {
     for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
     ctx->it_done = ctx->first_iters;
@@ -639,7 +643,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.gsip_samples = st[6];
   ctx->stats.gsip_iterations = (unsigned)st[7];
   ctx->stats.culled_points = st[8];
-  if (!ctx->persistent) {
+  if (!ctx->persistent || ctx->gsip_from > 0) {   // (persistent: only the iterations that ran as launches have counts)
     for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
     ctx->have_prev_nsolve = true;
   }
@@ -763,7 +767,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
     // (the persistent GSIP kernel has no per-iteration tails for a second batch to fill: it keeps one batch)
-    if (ctx->ub_full && ctx->want_batches == 0 && large && !ctx->persistent) rc = set_batches(ctx, ctx->ub_lazy ? 2 : 4);
+    if (ctx->ub_full && ctx->want_batches == 0 && large && !(ctx->persistent && ctx->gsip_from == 0)) rc = set_batches(ctx, ctx->ub_lazy ? 2 : 4);
   }
   fill_mode_stats(ctx);
   ctx->h_partial = ctx->h_out;
@@ -1371,6 +1375,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n > 0) ctx->n_cu = n;
   }
   if (const char *e = std::getenv("SVSDF_GSIP_GRACE")) ctx->gsip_grace = std::atoi(e);
+  if (const char *e = std::getenv("SVSDF_PERSISTENT_FROM")) ctx->gsip_from = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;

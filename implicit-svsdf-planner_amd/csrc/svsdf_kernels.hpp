@@ -1357,9 +1357,10 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
 // ---------------------------------------------------------------------------------------------
 // k_gsip: the whole GSIP loop of a batch in ONE persistent launch (experimental, env SVSDF_PERSISTENT=1).
 //
-// After k_round(0) opened round 1 of every interior point, the chain  k_solve(i) -> k_round(i+1)  (~10 dependent launch
-// pairs, each with a ramp-up and a tail, every point waiting for the slowest one of its iteration) is replaced by task
-// queues in device memory served by persistent waves:
+// After k_round(it0) (it0 = 0: right after round 1 of every interior point was opened; it0 > 0: the first it0 iterations
+// run as launches, the sparsely populated rest here) the chain  k_solve(i) -> k_round(i+1)  (~10 dependent launch pairs,
+// each with a ramp-up and a tail, every point waiting for the slowest one of its iteration) is replaced by task queues
+// in device memory served by persistent waves:
 //   SOLVE task (payload = sample slot >= 0): layer-1 scan unless seeded, layers 2-4, descent (descend_from_seed); the
 //                solve that brings its point's `pending` counter to zero queues the point's ROUND task
 //   ROUND task (payload = -2 - interior index): 32 lanes, round_point -- close / supplementary / finish / open -- and
@@ -1441,12 +1442,13 @@ template <int SHAPE, int MODE>
 __global__ void __launch_bounds__(kBlock, SVSDF_GSIP_WAVES)
 k_gsip(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
        const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_, const double *__restrict__ py_,
-       GsipState gs, size_t stride, double sel_delta, double sel_band, int all_round, int grace, int nq,
+       GsipState gs, size_t stride, double sel_delta, double sel_band, int all_round, int grace, int nq, int it0,
        double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
        BatchCtl *__restrict__ ctl) {
   constexpr int LP = 32;
   extern __shared__ double gsip_lds[];
-  const int n_int = ctl->n_active[0];   // interior points of this batch
+  // the launch takes over after k_round(it0): the points that round kept active, the solves it requested
+  const int n_int = ctl->n_active[it0 + 1];
   if (n_int <= 0) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
@@ -1460,7 +1462,7 @@ k_gsip(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   }
   const TrajL tr = stage_traj(trg, gsip_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
   const int start = ctl->start, count = ctl->count;
-  const unsigned n0 = (unsigned)ctl->n_solve[0];          // k_round(0)'s solve list
+  const unsigned n0 = (unsigned)ctl->n_solve[it0];        // k_round(it0)'s solve list
   const int *list0 = gs.solve + (size_t)start * kMaxSlots;
   const unsigned Qs = gsip_shard_slots(count, nq);        // ring slots per shard
   const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1648,7 +1650,7 @@ k_gsip(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   }
   if (lane == 0 && (te || tm)) {
     atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); atomicAdd(&ctl->stat_scan, tc);
-    if (tm) atomicAdd(&ctl->n_seed[1], (int)tm);
+    if (tm) atomicAdd(&ctl->n_seed[it0 + 1], (int)tm);
   }
 }
 

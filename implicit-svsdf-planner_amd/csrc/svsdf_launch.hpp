@@ -25,7 +25,7 @@ struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
 // running wave) -- *blocks_per_cu caches the occupancy query (0 = not asked yet) -- and derives the shard count from it
 struct GsipLaunch {
   const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py;
-  GsipState gs; size_t stride; double sel_delta, sel_band; int all_round, grace, n_cu; int *blocks_per_cu; double *res_sdf, *res_t, *res_gx, *res_gy;
+  GsipState gs; size_t stride; double sel_delta, sel_band; int all_round, grace, it0, n_cu; int *blocks_per_cu; double *res_sdf, *res_t, *res_gx, *res_gy;
   BatchCtl *ctl;
 };
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>

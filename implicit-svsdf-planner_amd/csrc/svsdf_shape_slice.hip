@@ -89,7 +89,7 @@ bool gsip_s(int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st,
     int nq = 1;                                                                                                     \
     while (nq * 2 <= kMaxShards && (unsigned)(nq * 2) * 8u <= waves) nq *= 2;   /* >= 8 waves per shard */           \
     hipLaunchKernelGGL((k_gsip<S, MODE>), dim3(g), dim3(block), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp, a.px, \
-                       a.py, a.gs, a.stride, a.sel_delta, a.sel_band, a.all_round, a.grace, nq, a.res_sdf,     \
+                       a.py, a.gs, a.stride, a.sel_delta, a.sel_band, a.all_round, a.grace, nq, a.it0, a.res_sdf,     \
                        a.res_t, a.res_gx, a.res_gy, a.ctl);                                                          \
   } while (0)
     if (mode == 2) GSIP(2); else if (mode == 1) GSIP(1); else GSIP(0);

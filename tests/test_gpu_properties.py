@@ -208,7 +208,9 @@ def test_persistent_gsip_kernel_is_invisible(built):
     import svsdf_amd
     from svsdf_amd import workload
     cases = [("C2", 30000, {}), ("C3", 40000, dict(SVSDF_UB_FULL=1)), ("NS", 30000, dict(SVSDF_UB_FULL=2)),
-             ("C5", 8000, dict(SVSDF_UB_FULL=1)), ("C4", 30000, dict(SVSDF_BATCHES=3)), ("C1", 700, {}), ("C1", 3, {})]
+             ("C5", 8000, dict(SVSDF_UB_FULL=1)), ("C4", 30000, dict(SVSDF_BATCHES=3)), ("C1", 700, {}), ("C1", 3, {}),
+             # hybrid: the first three iterations as launches, the sparsely populated rest in the persistent launch
+             ("C3", 30000, dict(SVSDF_UB_FULL=1, SVSDF_PERSISTENT_FROM=3, SVSDF_BATCHES=2))]
     for cfg, P, env in cases:
         w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
 
