@@ -61,6 +61,11 @@ struct Pose { double x, y, cs, sn; };
 constexpr int kChunk = 8;
 struct Chunk { double cx, cy, rb, slack; };  // slack: continuous-path allowance V_c * h for the exact cull (host)
 
+constexpr int kStatSlots = 32;
+struct StatSlot { unsigned long long solves, evals, scan, culled, pad[12]; };   // one 128-byte line
+__device__ __forceinline__ StatSlot *stat_slot(StatSlot *slots) {
+  return slots + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (kStatSlots - 1));
+}
 // Per-batch control block (device memory; the counters are cleared by k_prep at the start of
 // every evaluation, start/count are written by the host once per point upload).
 struct BatchCtl {
@@ -74,7 +79,10 @@ struct BatchCtl {
   // queues of the persistent GSIP kernel (k_gsip): SOLVE tasks = sample slots in gs.solve, ROUND tasks = interior indices
   unsigned q_done;   // persistent GSIP kernel: points finished
   int q_error;
-  unsigned long long stat_solves, stat_evals, stat_scan, stat_culled;
+  // work counters (statistics), added to by every wave at the end of a launch: one address takes ~80 M atomics / s
+  // (tools/experiments/coh_latency.hip), a full grid of waves ending together would queue up behind four words of one
+  // cache line -- the waves spread over kStatSlots lines, k_finish adds them up
+  StatSlot stat[kStatSlots];
 };
 
 // LDS view of the trajectory
@@ -333,7 +341,10 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     c.nonfinite = 0;
     c.q_done = 0u;
     c.q_error = 0;
-    c.stat_solves = 0ull; c.stat_evals = 0ull; c.stat_scan = 0ull; c.stat_culled = 0ull;
+  }
+  for (int i = threadIdx.x; i < nbatch * kStatSlots; i += blockDim.x) {
+    StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
+    ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull;
   }
   if (threadIdx.x == 0) {
     tr->N = N; tr->K = K; tr->dur = dur; tr->exact = exact;
@@ -765,9 +776,20 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   const TrajL tr = stage_traj(trg, solve_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
   const int li = Grp<G>::li();
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0;
+  // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
+  // the launch's cursor.  (All waves of a launch start together: with a fetch first, their 3000 atomics on one address
+  // take ~ 12 ns each, one after the other -- the last wave would start ~ 37 us late, in every launch of the chain.)
+  const long long per_wave = 64 / G;
+  const long long n_static = (long long)gridDim.x * (blockDim.x >> 6) * per_wave;
   for (int guard = 0; guard < (1 << 26); ++guard) {
-    long long wave_base;
-    const long long gq = fetch_work<G>(&ctl->work[work_idx], wave_base);
+    long long wave_base, gq;
+    if (guard == 0) {
+      wave_base = (long long)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * per_wave;
+      gq = wave_base + (long long)((threadIdx.x & 63) / G);
+    } else {
+      gq = fetch_work<G>(&ctl->work[work_idx], wave_base) + n_static;
+      wave_base += n_static;
+    }
     if (wave_base >= total) break;
     double px = 0.0, py = 0.0;
     size_t slot = 0;
@@ -808,8 +830,9 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tu += __shfl_xor(tu, m, 64);
   }
   if ((threadIdx.x & 63) == 0 && (te || tu)) {
-    atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); atomicAdd(&ctl->stat_scan, tc);
-    if (tu) atomicAdd(&ctl->stat_culled, tu);
+    StatSlot *ss = stat_slot(ctl->stat);
+    atomicAdd(&ss->evals, te); atomicAdd(&ss->solves, ts); atomicAdd(&ss->scan, tc);
+    if (tu) atomicAdd(&ss->culled, tu);
   }
 }
 
@@ -1350,7 +1373,10 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     unsigned long long tc = n_scan;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tc += __shfl_xor(tc, m, 64);
-    if ((threadIdx.x & 63) == 0 && tc) { atomicAdd(&ctl->stat_scan, tc); atomicAdd(&ctl->stat_evals, tc); }
+    if ((threadIdx.x & 63) == 0 && tc) {
+      StatSlot *ss = stat_slot(ctl->stat);
+      atomicAdd(&ss->scan, tc); atomicAdd(&ss->evals, tc);
+    }
   }
 }
 
@@ -1649,7 +1675,8 @@ k_gsip(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tm += __shfl_xor(tm, m, 64);
   }
   if (lane == 0 && (te || tm)) {
-    atomicAdd(&ctl->stat_evals, te); atomicAdd(&ctl->stat_solves, ts); atomicAdd(&ctl->stat_scan, tc);
+    StatSlot *ss = stat_slot(ctl->stat);
+    atomicAdd(&ss->evals, te); atomicAdd(&ss->solves, ts); atomicAdd(&ss->scan, tc);
     if (tm) atomicAdd(&ctl->n_seed[it0 + 1], (int)tm);
   }
 }
@@ -1808,7 +1835,10 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
     unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0;
     for (int b = 0; b < nbatch; ++b) {
-      so += ctl[b].stat_solves; ev += ctl[b].stat_evals; sc += ctl[b].stat_scan; cu += ctl[b].stat_culled;
+      for (int k = 0; k < kStatSlots; ++k) {
+        const StatSlot &ss = ctl[b].stat[k];
+        so += ss.solves; ev += ss.evals; sc += ss.scan; cu += ss.culled;
+      }
       in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
       rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
       for (int i = 0; i <= it_end; ++i) {
