@@ -76,9 +76,8 @@ struct BatchCtl {
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
   int pad;
-  // queues of the persistent GSIP kernel (k_gsip): SOLVE tasks = sample slots in gs.solve, ROUND tasks = interior indices
-  unsigned q_done;   // persistent GSIP kernel: points finished
-  int q_error;
+  unsigned q_done;   // persistent GSIP kernel (k_gsip): points finished, handed in by the waves as they run dry
+  int q_error;       // k_gsip gave up (2 ring full, 3 poll cap, 4 round without samples): the host falls back to the chain
   // work counters (statistics), added to by every wave at the end of a launch: one address takes ~80 M atomics / s
   // (tools/experiments/coh_latency.hip), a full grid of waves ending together would queue up behind four words of one
   // cache line -- the waves spread over kStatSlots lines, k_finish adds them up
