@@ -37,8 +37,8 @@ def c2(built):
 
 
 def test_c2_full_size_solver_variants_bit_identical(c2):
-    """Pruned layer-1 scan == full scan, and every lane-group width gives the same (sdf, t*, grad)
-    for all 100k points (the restructurings are exact, not approximate)."""
+    """Pruned layer-1 scan == full scan, every lane-group width and the persistent GSIP kernel give the same
+    (sdf, t*, grad) for all 100k points (the restructurings are exact, not approximate)."""
     def run(env):
         def go():
             c = _ctx(c2)
@@ -56,7 +56,11 @@ def test_c2_full_size_solver_variants_bit_identical(c2):
                 dict(SVSDF_G=2, SVSDF_G_LATE=2, SVSDF_PRUNE=1, SVSDF_BATCHES=4),
                 dict(SVSDF_G=8, SVSDF_G_LATE=8, SVSDF_PRUNE=1, SVSDF_BATCHES=3),
                 dict(SVSDF_G=16, SVSDF_G_LATE=32, SVSDF_PRUNE=1, SVSDF_BATCHES=1),
-                dict(SVSDF_G=32, SVSDF_G_LATE=16, SVSDF_PRUNE=1, SVSDF_BATCHES=2)):
+                dict(SVSDF_G=32, SVSDF_G_LATE=16, SVSDF_PRUNE=1, SVSDF_BATCHES=2),
+                # the GSIP loop as ONE persistent launch (k_gsip, device-side task queues), and as launches for three
+                # iterations + the persistent launch for the rest
+                dict(SVSDF_PERSISTENT=1, SVSDF_BATCHES=1),
+                dict(SVSDF_PERSISTENT=1, SVSDF_PERSISTENT_FROM=3, SVSDF_BATCHES=2)):
         out, st = run(env)
         for a, b in zip(out, ref):
             assert np.array_equal(a, b), env
