@@ -30,6 +30,7 @@
 #define SVSDF_API_TU   // this translation unit compiles the shape-independent kernels of svsdf_kernels.hpp
 #include "svsdf_launch.hpp"
 #include "svsdf_lbfgs.hpp"
+#include "svsdf_mesh.hpp"
 #include "svsdf_minco.hpp"
 #include "svsdf_points.hpp"
 
@@ -89,7 +90,8 @@ struct svsdf_ctx {
   hipStream_t bstream[kMaxBatches] = {};      // one stream per point batch
   hipEvent_t ev_prep = nullptr, ev_done[kMaxBatches] = {};
   ShapeParams sp{};
-  double *d_poly = nullptr;
+  unsigned char *d_poly = nullptr;   // Polygon: one device blob [PolyAccel | edges | cell offsets | slab offsets | candidates | slab edges]
+  std::vector<double> poly_xy;       // Polygon: the outline as given (host copy)
   std::string err;
 
   // points: this rank's shard, Morton-sorted, split into nbatch contiguous batches
@@ -898,36 +900,102 @@ int set_batches(svsdf_ctx *ctx, int nb) {
   return SVSDF_OK;
 }
 
-// Plan and upload this context's stripe of the cloud ON THE DEVICE: d_xyz (AoS, P x 3 doubles, on ctx's device) ->
-// bounding box -> Morton keys -> radix sort (hipcub, all 64 bits of (Morton code << 32 | input index): the same
-// order as the host planner's stable sort by Morton code; a partial bit range [32, 64) came back unsorted) ->
-// gather of stripe (rk, ws) into the SoA arrays + original indices.  Same key formula as the host planner
-// (svsdf_shard_plan), so both give the same order (tests/test_points_upload_gpu.py).  1 M points: ~2 ms on the
-// device (+ ~4 ms PCIe when the cloud comes from host memory) against 29 ms for round 1's host radix sort.
-int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, int ws) {
+// Plan of a cloud ON THE DEVICE: d_xyz (AoS, P x 3 doubles, on the planner's device) -> bounding box -> Morton keys ->
+// radix sort (hipcub, all 64 bits of (Morton code << 32 | input index): the same order as the host planner's stable
+// sort by Morton code; a partial bit range [32, 64) came back unsorted).  Same key formula as the host planner
+// (svsdf_shard_plan), so both give the same order (tests/test_points_upload_gpu.py).  1 M points: ~2 ms on the device
+// (+ ~4 ms PCIe when the cloud comes from host memory) against 29 ms for round 1's host radix sort.
+// The plan is made ONCE per cloud; every context of a multi-device group then takes its stripe from it (take_stripe).
+struct CloudPlan {
+  int device = 0;
+  const double *d_xyz = nullptr;
+  size_t P = 0;
+  double *d_part = nullptr;
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  const unsigned long long *sorted = nullptr;
+  void *d_tmp = nullptr;
+  void release() {
+    (void)hipSetDevice(device);
+    for (void *q : {(void *)d_part, (void *)d_keys, (void *)d_keys2, d_tmp})
+      if (q) (void)hipFree(q);
+    d_part = nullptr; d_keys = d_keys2 = nullptr; d_tmp = nullptr; sorted = nullptr;
+  }
+};
+
+int plan_cloud(svsdf_ctx *ctx, const double *d_xyz, size_t P, CloudPlan &plan) {
+  plan.device = ctx->device;
+  plan.d_xyz = d_xyz;
+  plan.P = P;
+  if (P > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points (max 2^31 - 1 per call)");
+  if (P == 0) return SVSDF_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+#define UPCHK(expr)                                                                                                  \
+  do {                                                                                                               \
+    hipError_t e_ = (expr);                                                                                          \
+    if (e_ != hipSuccess) { plan.release(); return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+  } while (0)
+  const unsigned grid = (unsigned)std::min<size_t>((P + kBlock - 1) / kBlock, 1024);
+  UPCHK(hipMalloc((void **)&plan.d_part, (size_t)grid * 4 * sizeof(double)));
+  UPCHK(hipMalloc((void **)&plan.d_keys, P * sizeof(unsigned long long)));
+  UPCHK(hipMalloc((void **)&plan.d_keys2, P * sizeof(unsigned long long)));
+  UPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_points_bbox, dim3(grid), dim3(kBlock), 0, st, d_xyz, P, plan.d_part, ctx->d_nonfinite);
+  std::vector<double> hp((size_t)grid * 4);
+  int bad = 0;
+  UPCHK(hipMemcpyAsync(hp.data(), plan.d_part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  UPCHK(hipMemcpyAsync(&bad, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+  UPCHK(hipStreamSynchronize(st));
+  if (bad) { plan.release(); return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite query point"); }
+  double xmin = hp[0], xmax = hp[1], ymin = hp[2], ymax = hp[3];
+  for (unsigned b = 1; b < grid; ++b) {
+    xmin = std::min(xmin, hp[4 * b]); xmax = std::max(xmax, hp[4 * b + 1]);
+    ymin = std::min(ymin, hp[4 * b + 2]); ymax = std::max(ymax, hp[4 * b + 3]);
+  }
+  const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
+  const int keep = ((ctx->cfg.flags & SVSDF_FLAG_KEEP_INPUT_ORDER) || P <= 1) ? 1 : 0;
+  hipLaunchKernelGGL(k_points_keys, dim3(grid), dim3(kBlock), 0, st, d_xyz, P, xmin, ymin, ext, keep, plan.d_keys);
+  plan.sorted = plan.d_keys;
+  if (!keep) {
+    size_t tmp_bytes = 0;
+    UPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, plan.d_keys, plan.d_keys2, (int)P, 0, 64, st));
+    UPCHK(hipMalloc(&plan.d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    UPCHK(hipcub::DeviceRadixSort::SortKeys(plan.d_tmp, tmp_bytes, plan.d_keys, plan.d_keys2, (int)P, 0, 64, st));
+    plan.sorted = plan.d_keys2;
+  }
+  UPCHK(hipStreamSynchronize(st));
+  UPCHK(hipGetLastError());
+#undef UPCHK
+  return SVSDF_OK;
+}
+
+// Context `ctx` takes stripe (rk, ws) of a planned cloud: gather into its SoA arrays + original indices.  The planner
+// may be another context (multi-device group): then the stripe is gathered on the planner's device into a staging
+// buffer and handed over with hipMemcpyPeer (over xGMI between two GPUs; the same call when both are one device).
+int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int rk, int ws) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipDeviceSynchronize());
   ws = std::max(1, ws);
+  const size_t P = plan.P;
   // until the new cloud is completely in place the context holds none (a failed upload must not leave the old point
   // count with re-allocated buffers)
   ctx->P = 0;
   ctx->points_set = false;
   ctx->saved_nbatch = 0;
   const size_t Ps = (P > (size_t)rk) ? (P - (size_t)rk + (size_t)ws - 1) / (size_t)ws : 0;
-  if (P > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points (max 2^31 - 1 per call)");
   if (Ps * kMaxSlots > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points per shard (max ~89M)");
   ctx->shard_idx.assign(Ps, 0ll);
   int rc = alloc_point_buffers(ctx, Ps);
   if (rc) return rc;
-  hipStream_t st = ctx->stream;
-  if (P > 0) {
-    const unsigned grid = (unsigned)std::min<size_t>((P + kBlock - 1) / kBlock, 1024);
-    double *d_part = nullptr;
-    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  if (Ps > 0) {
+    const bool local = planner == ctx;
+    HIPCHK(hipSetDevice(planner->device));
+    hipStream_t st = planner->stream;
     long long *d_idx = nullptr;
-    void *d_tmp = nullptr;
+    double *d_sx = nullptr, *d_sy = nullptr;
     auto cleanup = [&]() {
-      for (void *q : {(void *)d_part, (void *)d_keys, (void *)d_keys2, (void *)d_idx, d_tmp})
+      (void)hipSetDevice(planner->device);
+      for (void *q : {(void *)d_idx, (void *)d_sx, (void *)d_sy})
         if (q) (void)hipFree(q);
     };
 #define UPCHK(expr)                                                                                                  \
@@ -935,44 +1003,25 @@ int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, i
     hipError_t e_ = (expr);                                                                                          \
     if (e_ != hipSuccess) { cleanup(); return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
   } while (0)
-    UPCHK(hipMalloc((void **)&d_part, (size_t)grid * 4 * sizeof(double)));
-    UPCHK(hipMalloc((void **)&d_keys, P * sizeof(unsigned long long)));
-    UPCHK(hipMalloc((void **)&d_keys2, P * sizeof(unsigned long long)));
-    UPCHK(hipMalloc((void **)&d_idx, std::max<size_t>(Ps, 1) * sizeof(long long)));
-    UPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_points_bbox, dim3(grid), dim3(kBlock), 0, st, d_xyz, P, d_part, ctx->d_nonfinite);
-    std::vector<double> hp((size_t)grid * 4);
-    int bad = 0;
-    UPCHK(hipMemcpyAsync(hp.data(), d_part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    UPCHK(hipMemcpyAsync(&bad, ctx->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
-    UPCHK(hipStreamSynchronize(st));
-    if (bad) { cleanup(); return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite query point"); }
-    double xmin = hp[0], xmax = hp[1], ymin = hp[2], ymax = hp[3];
-    for (unsigned b = 1; b < grid; ++b) {
-      xmin = std::min(xmin, hp[4 * b]); xmax = std::max(xmax, hp[4 * b + 1]);
-      ymin = std::min(ymin, hp[4 * b + 2]); ymax = std::max(ymax, hp[4 * b + 3]);
+    UPCHK(hipMalloc((void **)&d_idx, Ps * sizeof(long long)));
+    if (!local) {
+      UPCHK(hipMalloc((void **)&d_sx, Ps * sizeof(double)));
+      UPCHK(hipMalloc((void **)&d_sy, Ps * sizeof(double)));
     }
-    const double ext = std::max(std::max(xmax - xmin, ymax - ymin), 1e-12);
-    const int keep = ((ctx->cfg.flags & SVSDF_FLAG_KEEP_INPUT_ORDER) || P <= 1) ? 1 : 0;
-    hipLaunchKernelGGL(k_points_keys, dim3(grid), dim3(kBlock), 0, st, d_xyz, P, xmin, ymin, ext, keep, d_keys);
-    const unsigned long long *sorted = d_keys;
-    if (!keep) {
-      size_t tmp_bytes = 0;
-      UPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)P, 0, 64, st));
-      UPCHK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-      UPCHK(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_keys2, (int)P, 0, 64, st));
-      sorted = d_keys2;
-    }
-    if (Ps > 0) {
-      const unsigned g2 = (unsigned)std::min<size_t>((Ps + kBlock - 1) / kBlock, 1024);
-      hipLaunchKernelGGL(k_points_gather, dim3(g2), dim3(kBlock), 0, st, d_xyz, sorted, P, rk, ws, Ps, ctx->d_px, ctx->d_py, d_idx);
-      UPCHK(hipMemcpyAsync(ctx->shard_idx.data(), d_idx, Ps * sizeof(long long), hipMemcpyDeviceToHost, st));
-    }
+    const unsigned g2 = (unsigned)std::min<size_t>((Ps + kBlock - 1) / kBlock, 1024);
+    hipLaunchKernelGGL(k_points_gather, dim3(g2), dim3(kBlock), 0, st, plan.d_xyz, plan.sorted, P, rk, ws, Ps,
+                       local ? ctx->d_px : d_sx, local ? ctx->d_py : d_sy, d_idx);
+    UPCHK(hipMemcpyAsync(ctx->shard_idx.data(), d_idx, Ps * sizeof(long long), hipMemcpyDeviceToHost, st));
     UPCHK(hipStreamSynchronize(st));
     UPCHK(hipGetLastError());
+    if (!local) {
+      UPCHK(hipMemcpyPeer(ctx->d_px, ctx->device, d_sx, planner->device, Ps * sizeof(double)));
+      UPCHK(hipMemcpyPeer(ctx->d_py, ctx->device, d_sy, planner->device, Ps * sizeof(double)));
+    }
 #undef UPCHK
     cleanup();
   }
+  HIPCHK(hipSetDevice(ctx->device));
   ctx->P = Ps;
   ctx->points_set = true;
   // batches: contiguous ranges of the sorted shard, pipelined on separate streams (one until the GSIP bound mode is
@@ -992,6 +1041,42 @@ int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, i
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
   }
   return SVSDF_OK;
+}
+
+// single-device context: plan + its own stripe
+int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, int ws) {
+  CloudPlan plan;
+  int rc = plan_cloud(ctx, d_xyz, P, plan);
+  if (rc) { ctx->P = 0; ctx->points_set = false; return rc; }
+  rc = take_stripe(ctx, ctx, plan, rk, ws);
+  plan.release();
+  return rc;
+}
+
+// multi-device group: the cloud (on device subs[0]) is planned ONCE there, every sub-context takes its stripe
+int upload_group_device(svsdf_ctx *ctx, const double *d_xyz, size_t P) {
+  const int G = (int)ctx->subs.size();
+  svsdf_ctx *s0 = ctx->subs[0];
+  CloudPlan plan;
+  int rc = plan_cloud(s0, d_xyz, P, plan);
+  for (int k = 0; k < G && !rc; ++k) {
+    rc = take_stripe(ctx->subs[k], s0, plan, ctx->cfg.rank * G + k, ctx->cfg.world_size * G);
+    if (rc) {
+      ctx->err = "device " + std::to_string(ctx->subs[k]->device) + " (stripe " + std::to_string(k) + "): " + ctx->subs[k]->err;
+      g_last_error = ctx->err;
+    }
+  }
+  if (rc && ctx->err.empty()) ctx->err = s0->err;
+  plan.release();
+  ctx->P = 0;
+  ctx->shard_idx.clear();
+  for (svsdf_ctx *s : ctx->subs) {
+    if (rc) { s->P = 0; s->points_set = false; }
+    ctx->P += s->P;
+    ctx->shard_idx.insert(ctx->shard_idx.end(), s->shard_idx.begin(), s->shard_idx.end());
+  }
+  ctx->points_set = rc == SVSDF_OK;
+  return rc;
 }
 
 // ---- in-process multi-GPU group ---------------------------------------------------------------------
@@ -1125,42 +1210,23 @@ int run_pipeline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   return ctx->subs.empty() ? run_pipeline_leaf(ctx, N, coeffs, T) : run_pipeline_group(ctx, N, coeffs, T);
 }
 
-// Stage the host cloud on the device (one H2D of the AoS array) and plan + gather there.
-int upload_from_host(svsdf_ctx *ctx, const double *xyz, size_t P, int rk, int ws) {
-  HIPCHK(hipSetDevice(ctx->device));
+// Stage the host cloud on the device (one H2D of the AoS array) and plan + gather there; a multi-device group stages
+// and plans it once, on its first device.
+int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  if (P > 0xffffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points");
+  const auto t0 = std::chrono::steady_clock::now();
+  svsdf_ctx *s0 = ctx->subs.empty() ? ctx : ctx->subs[0];
+  HIPCHK(hipSetDevice(s0->device));
   double *d_xyz = nullptr;
   if (P) {
     HIPCHK(hipMalloc((void **)&d_xyz, 3 * P * sizeof(double)));
     const hipError_t e = hipMemcpy(d_xyz, xyz, 3 * P * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d_xyz); return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e, "upload of the query points failed"); }
   }
-  const int rc = upload_shard_device(ctx, d_xyz, P, rk, ws);
-  if (d_xyz) (void)hipFree(d_xyz);
-  return rc;
-}
-
-int set_points_host(svsdf_ctx *ctx, const double *xyz, size_t P) {
-  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
-  if (P > 0xffffffffull) return fail(ctx, SVSDF_ERR_INVALID, "too many points");
-  const auto t0 = std::chrono::steady_clock::now();
-  int rc = SVSDF_OK;
-  if (ctx->subs.empty()) {
-    rc = upload_from_host(ctx, xyz, P, ctx->cfg.rank, ctx->cfg.world_size);
-  } else {
-    // every device plans the whole cloud itself (a ~2 ms sort, in parallel on the devices' own host threads and
-    // PCIe links) and keeps its stripe
-    const int G = (int)ctx->subs.size();
-    rc = group_run(ctx, [&](int k) -> int {
-      return upload_from_host(ctx->subs[k], xyz, P, ctx->cfg.rank * G + k, ctx->cfg.world_size * G);
-    });
-    ctx->P = 0;
-    ctx->shard_idx.clear();
-    for (svsdf_ctx *s : ctx->subs) {
-      ctx->P += s->P;
-      ctx->shard_idx.insert(ctx->shard_idx.end(), s->shard_idx.begin(), s->shard_idx.end());
-    }
-    ctx->points_set = rc == SVSDF_OK;
-  }
+  const int rc = ctx->subs.empty() ? upload_shard_device(ctx, d_xyz, P, ctx->cfg.rank, ctx->cfg.world_size)
+                                   : upload_group_device(ctx, d_xyz, P);
+  if (d_xyz) { (void)hipSetDevice(s0->device); (void)hipFree(d_xyz); }
   ctx->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (svsdf_ctx *s : ctx->subs) s->setup_ms = ctx->setup_ms;
   return rc;
@@ -1343,20 +1409,43 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   sp.r_bound = 0.0;
   sp.identity = (sp.tx == 0.0 && sp.ty == 0.0 && sp.r00 == 1.0 && sp.r01 == 0.0 && sp.r10 == 0.0 && sp.r11 == 1.0) ? 1 : 0;
   sp.nverts = 0;
-  sp.verts = nullptr;
+  sp.accel = nullptr;
   if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
-    std::vector<double> v;
+    std::vector<double> &v = ctx->poly_xy;
     if (cfg->polygon_xy && cfg->polygon_nverts >= 3) {
-      const int n = std::min(cfg->polygon_nverts, SVSDF_MAX_POLY_VERTS);
-      v.assign(cfg->polygon_xy, cfg->polygon_xy + 2 * n);
+      if (cfg->polygon_nverts > SVSDF_MAX_POLY_VERTS)
+        return bail("svsdf_create: polygon_nverts exceeds SVSDF_MAX_POLY_VERTS (" + std::to_string(SVSDF_MAX_POLY_VERTS) + ")");
+      v.assign(cfg->polygon_xy, cfg->polygon_xy + 2 * (size_t)cfg->polygon_nverts);
     } else {
       v = {6, -0.1, 6, 0.1, -6, 0.1, -6, -0.1};  // SWM:363-369
     }
-    if (hipMalloc((void **)&ctx->d_poly, v.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc polygon failed");
-    if (hipMemcpy(ctx->d_poly, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    // candidate lists of the outline (svsdf_polygon.hpp), then one upload: the header's pointers are device addresses
+    PolyAccelHost pa;
+    if (!build_poly_accel(v.data(), (int)(v.size() / 2), pa)) return bail("svsdf_create: polygon outline rejected (non-finite vertex?)");
+    auto align = [](size_t o) { return (o + 63) & ~(size_t)63; };
+    const size_t o_edges = align(sizeof(PolyAccel));
+    const size_t o_cell = align(o_edges + pa.edges.size() * sizeof(PolyEdge));
+    const size_t o_slab = align(o_cell + pa.cell_off.size() * sizeof(unsigned));
+    const size_t o_cand = align(o_slab + pa.slab_off.size() * sizeof(unsigned));
+    const size_t o_sedg = align(o_cand + pa.cand.size() * sizeof(unsigned short));
+    const size_t total = align(o_sedg + pa.slab_edges.size() * sizeof(unsigned short));
+    if (hipMalloc((void **)&ctx->d_poly, total) != hipSuccess) return bail("hipMalloc polygon failed");
+    std::vector<unsigned char> blob(total, 0);
+    pa.hdr.edges = reinterpret_cast<const PolyEdge *>(ctx->d_poly + o_edges);
+    pa.hdr.cell_off = reinterpret_cast<const unsigned *>(ctx->d_poly + o_cell);
+    pa.hdr.slab_off = reinterpret_cast<const unsigned *>(ctx->d_poly + o_slab);
+    pa.hdr.cand = reinterpret_cast<const unsigned short *>(ctx->d_poly + o_cand);
+    pa.hdr.slab_edges = reinterpret_cast<const unsigned short *>(ctx->d_poly + o_sedg);
+    std::memcpy(blob.data(), &pa.hdr, sizeof(PolyAccel));
+    std::memcpy(blob.data() + o_edges, pa.edges.data(), pa.edges.size() * sizeof(PolyEdge));
+    std::memcpy(blob.data() + o_cell, pa.cell_off.data(), pa.cell_off.size() * sizeof(unsigned));
+    std::memcpy(blob.data() + o_slab, pa.slab_off.data(), pa.slab_off.size() * sizeof(unsigned));
+    std::memcpy(blob.data() + o_cand, pa.cand.data(), pa.cand.size() * sizeof(unsigned short));
+    std::memcpy(blob.data() + o_sedg, pa.slab_edges.data(), pa.slab_edges.size() * sizeof(unsigned short));
+    if (hipMemcpy(ctx->d_poly, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess)
       return bail("hipMemcpy polygon failed");
     sp.nverts = (int)(v.size() / 2);
-    sp.verts = ctx->d_poly;
+    sp.accel = reinterpret_cast<const PolyAccel *>(ctx->d_poly);
     ctx->cfg.polygon_nverts = sp.nverts;
   }
   ctx->G_env = 0;
@@ -1407,12 +1496,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   {  // shape bound radius R with sdf_shape(q) >= |q| - R for every q: the shape's circumradius about the body origin
      // (analytic, per shape; shape_circumradius above) plus the length of its offset (Shape.hpp:281-294).  The polar
      // sample of |q| - sdf(q) (k_rbound, out to 60 m) is kept as a self-check of that bound, not as its source.
-    std::vector<double> pv;
-    if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
-      pv.resize(2 * (size_t)sp.nverts);
-      if (hipMemcpy(pv.data(), ctx->d_poly, pv.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return bail("hipMemcpy polygon failed");
-    }
-    const double r0 = shape_circumradius(cfg->shape_id, pv.data(), sp.nverts);
+    const double r0 = shape_circumradius(cfg->shape_id, ctx->poly_xy.data(), sp.nverts);
     const double analytic = (r0 + std::hypot(sp.tx, sp.ty)) * (1.0 + 1e-12) + 1e-6;
     if (hipMemset(ctx->d_out, 0, sizeof(double)) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;
@@ -1485,11 +1569,12 @@ int svsdf_set_points_device(svsdf_ctx *ctx, const double *d_xyz_aos, size_t P) {
     ctx->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
   }
-  // multi-device context: the other devices need the cloud too -- one D2H, then every device uploads and plans
-  HIPCHK(hipSetDevice(ctx->subs[0]->device));
-  std::vector<double> h(3 * P);
-  if (P) HIPCHK(hipMemcpy(h.data(), d_xyz_aos, 3 * P * sizeof(double), hipMemcpyDeviceToHost));
-  return set_points_host(ctx, h.data(), P);
+  // multi-device context: planned once where the cloud lives (devices[0]), stripes handed to the other devices
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = upload_group_device(ctx, d_xyz_aos, P);
+  ctx->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (svsdf_ctx *s : ctx->subs) s->setup_ms = ctx->setup_ms;
+  return rc;
 }
 
 size_t svsdf_num_points(const svsdf_ctx *ctx) { return ctx ? ctx->P : 0; }
@@ -1814,6 +1899,33 @@ int svsdf_pcd_read_ascii(const char *path, float *xyz, size_t capacity, size_t *
     std::copy(v.begin(), v.end(), xyz);
   }
   return SVSDF_OK;
+}
+
+// ---- mesh shapes (host) ------------------------------------------------------------------------------
+static int outline_out(const std::vector<double> &xy, double *xy_out, size_t capacity_verts, size_t *count) {
+  *count = xy.size() / 2;
+  if (xy_out) {
+    if (capacity_verts < *count) return SVSDF_ERR_INVALID;
+    std::copy(xy.begin(), xy.end(), xy_out);
+  }
+  return SVSDF_OK;
+}
+int svsdf_mesh_outline(const double *V, size_t nv, const int *F, size_t nf, double z0, double *xy_out,
+                       size_t capacity_verts, size_t *count, int *loops) {
+  if (!V || !F || !count || !std::isfinite(z0)) return SVSDF_ERR_INVALID;
+  std::vector<double> xy;
+  if (!svsdf_host::mesh_outline(V, nv, F, nf, z0, xy, loops)) return fail(nullptr, SVSDF_ERR_INVALID, "svsdf_mesh_outline: no closed cross-section at z0");
+  return outline_out(xy, xy_out, capacity_verts, count);
+}
+int svsdf_mesh_outline_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *count,
+                           int *loops) {
+  if (!obj_path || !count || !std::isfinite(z0)) return SVSDF_ERR_INVALID;
+  std::vector<double> V, xy;
+  std::vector<int> F;
+  if (!svsdf_host::read_obj(obj_path, V, F)) return fail(nullptr, SVSDF_ERR_INVALID, std::string("svsdf_mesh_outline_obj: cannot read ") + obj_path);
+  if (!svsdf_host::mesh_outline(V.data(), V.size() / 3, F.data(), F.size() / 3, z0, xy, loops))
+    return fail(nullptr, SVSDF_ERR_INVALID, "svsdf_mesh_outline_obj: no closed cross-section at z0");
+  return outline_out(xy, xy_out, capacity_verts, count);
 }
 
 // ---- host MINCO helpers --------------------------------------------------------------------------

@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "svsdf_polygon.hpp"
+
 namespace svsdf {
 
 constexpr double kPI = 3.14159265358979323846;  // SHP:31
@@ -27,8 +29,8 @@ struct ShapeParams {
   double c0x, c0y;            // shape-specific (cos,sin) pair: horseshoe c / pie c / arc sc
   double r_bound;             // conservative circumradius about the body-frame origin (culling)
   int identity;               // trans == 0 and Rotate == I (poly_params = 0): the transform is exact identity
-  int nverts;                 // Polygon
-  const double *verts;        // Polygon: device pointer, xy interleaved
+  int nverts;                 // Polygon: outline vertices
+  const PolyAccel *accel;     // Polygon: device pointer to the outline's edges + candidate lists (svsdf_polygon.hpp)
 };
 
 // std::max / std::min.  Strict builds keep the compare+select form; the default uses v_max_f64 /
@@ -237,77 +239,8 @@ __device__ __forceinline__ double sdf_arc(double px, double py, double scx, doub
   return (condition ? dist1 : dist2) - rb;
 }
 
-// Polygon: SHP:1370-1401 (edge helpers) + SHP:1448-1476.  No trans/Rotate (as the reference).
-// isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
-// atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
-// opposite signs of y and the vector with y > 0 leading the other by more than pi counter-clockwise, i.e.
-// sign(cross(s2, e2)) -- decided without atan2 unless the angle difference is within ~1e-9 rad of 0 or pi
-// (sin^2 <= 1e-18), where the rounding of the two atan2 values (~1e-16) could matter and the reference
-// formula itself is evaluated.
-__device__ __forceinline__ bool poly_cross_ray(double s2x, double s2y, double e2x, double e2y) {
-  const double crs = s2x * e2y - s2y * e2x;
-  const double n2 = (s2x * s2x + s2y * s2y) * (e2x * e2x + e2y * e2y);
-  if (s2y != 0.0 && e2y != 0.0 && crs * crs > 1e-18 * n2) {
-    const bool sneg = s2y < 0.0, eneg = e2y < 0.0;
-    return (sneg != eneg) && ((crs < 0.0) == eneg);
-  }
-  double theta_s = atan2(s2y, s2x);
-  double theta_e = atan2(e2y, e2x);
-  theta_s = (theta_s < 0.0) ? (theta_s + 2 * kPI) : theta_s;
-  theta_e = (theta_e < 0.0) ? (theta_e + 2 * kPI) : theta_e;
-  return !(fabs(theta_s - theta_e) < kPI);
-}
-
-// Polygon::getonlySDF (SHP:1448-1476) with the closest point (needed by the analytic gradient SHP:1505-1531).
-__device__ inline double sdf_polygon(const ShapeParams &sp, double x, double y, double *cminx,
-                                     double *cminy) {
-  double dis_min = 1e9, mx = 0.0, my = 0.0;
-  int rs = 0;
-  const int n = sp.nverts;
-  for (int i = 0; i < n; ++i) {
-    const int j = (i + 1 == n) ? 0 : i + 1;
-    const double sx = sp.verts[2 * i], sy = sp.verts[2 * i + 1];
-    const double ex = sp.verts[2 * j], ey = sp.verts[2 * j + 1];
-    // dis2Seg
-    const double vx = ex - sx, vy = ey - sy;
-    const double wx = x - sx, wy = y - sy;
-    double t = (wx * vx + wy * vy) / (vx * vx + vy * vy);
-    if (t < 0.0) t = 0.0;
-    else if (t > 1.0) t = 1.0;
-    const double cx = sx + t * vx, cy = sy + t * vy;
-    const double dis = norm2(x - cx, y - cy);
-    if (dis < dis_min) { dis_min = dis; mx = cx; my = cy; }
-    if (poly_cross_ray(sx - x, sy - y, ex - x, ey - y)) rs++;
-  }
-  if (cminx) { *cminx = mx; *cminy = my; }
-  return (rs % 2 == 0) ? dis_min : -dis_min;
-}
-
-// Value only (the hot path): min_i sqrt(d2_i) == sqrt(min_i d2_i) exactly -- sqrt is correctly rounded and
-// monotone and the d2_i are the same numbers norm() would square-root -- so one sqrt per evaluation instead of
-// one per edge; which edge attains the minimum (ties of rounded roots) only matters for the closest point above.
-__device__ inline double sdf_polygon_value(const ShapeParams &sp, double x, double y) {
-  double d2_min = 1e300;
-  int rs = 0;
-  const int n = sp.nverts;
-  for (int i = 0; i < n; ++i) {
-    const int j = (i + 1 == n) ? 0 : i + 1;
-    const double sx = sp.verts[2 * i], sy = sp.verts[2 * i + 1];
-    const double ex = sp.verts[2 * j], ey = sp.verts[2 * j + 1];
-    const double vx = ex - sx, vy = ey - sy;
-    const double wx = x - sx, wy = y - sy;
-    double t = (wx * vx + wy * vy) / (vx * vx + vy * vy);
-    if (t < 0.0) t = 0.0;
-    else if (t > 1.0) t = 1.0;
-    const double cx = sx + t * vx, cy = sy + t * vy;
-    const double dx = x - cx, dy = y - cy;
-    d2_min = dmin(d2_min, dx * dx + dy * dy);
-    if (poly_cross_ray(sx - x, sy - y, ex - x, ey - y)) rs++;
-  }
-  const double dis_min = dmin(sqrt(d2_min), 1e9);   // the reference's running minimum starts at 1e9
-  return (rs % 2 == 0) ? dis_min : -dis_min;
-}
-
+// Polygon (SHP:1352-1531; no trans/Rotate, as the reference): svsdf_polygon.hpp -- the reference's loop over all edges,
+// restricted to the edges that can matter for the query's cell / slab (same bits).
 // The shape formula proper, on the shape-local point (after trans / Rotate).
 template <int SHAPE>
 __device__ __forceinline__ double shape_core(const ShapeParams &sp, double px, double py) {
@@ -332,7 +265,7 @@ __device__ __forceinline__ double shape_core(const ShapeParams &sp, double px, d
 template <int SHAPE>
 __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, double y) {
   if constexpr (SHAPE == kPolygon) {
-    return sdf_polygon_value(sp, x, y);
+    return poly_sdf<false>(*sp.accel, x, y, nullptr, nullptr);
   } else {
     double px = x, py = y;
     if (!sp.identity) {  // wave-uniform; with trans = 0, Rotate = I the products below are exact no-ops
@@ -364,7 +297,7 @@ __device__ __forceinline__ void shape_grad(const ShapeParams &sp, double x, doub
                                            double &gy) {
   if constexpr (SHAPE == kPolygon) {
     double cx, cy;
-    const double sd = sdf_polygon(sp, x, y, &cx, &cy);
+    const double sd = poly_sdf<true>(*sp.accel, x, y, &cx, &cy);
     double vx = x - cx, vy = y - cy;
     const double z = vx * vx + vy * vy;
     if (z > 0.0) { const double n = sqrt(z); vx = vx / n; vy = vy / n; }

@@ -27,6 +27,7 @@ EXPORTS = [
     "svsdf_check_sub_sw_collision", "svsdf_shape_kernels",
     "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
+    "svsdf_mesh_outline", "svsdf_mesh_outline_obj",
 ]
 
 
@@ -142,6 +143,9 @@ def lib():
     L.svsdf_check_sub_sw_collision.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, C.POINTER(C.c_size_t), _dp, _u8p]
     L.svsdf_shape_kernels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p, _dp,
                                       C.POINTER(C.c_int)]
+    L.svsdf_mesh_outline.argtypes = [_dp, C.c_size_t, _ip, C.c_size_t, C.c_double, _dp, C.c_size_t,
+                                     C.POINTER(C.c_size_t), _ip]
+    L.svsdf_mesh_outline_obj.argtypes = [C.c_char_p, C.c_double, _dp, C.c_size_t, C.POINTER(C.c_size_t), _ip]
     _LIB = L
     return L
 
@@ -174,6 +178,32 @@ def minco_coeffs(head_state, tail_state, inPs, T):
     if rc:
         raise SvsdfError(f"svsdf_minco_coeffs failed: {rc}")
     return out.reshape(3, 6 * N).T.copy()
+
+
+def mesh_outline(V, F, z0=0.0):
+    """z = z0 cross-section of a triangle mesh (V (nv, 3), F (nf, 3) zero-based) -> (outline (n, 2), closed loops
+    found); pure host (svsdf_mesh_outline).  The outline is what `polygon=` of SvsdfContext takes: BASELINE config 5."""
+    V = _f64(V).reshape(-1, 3)
+    F = np.ascontiguousarray(F, dtype=np.int32).reshape(-1, 3)
+    n, loops = C.c_size_t(), C.c_int()
+    ip = C.POINTER(C.c_int)
+    rc = lib().svsdf_mesh_outline(_p(V), len(V), F.ctypes.data_as(ip), len(F), float(z0), None, 0, C.byref(n), C.byref(loops))
+    if rc:
+        raise SvsdfError(f"svsdf_mesh_outline failed: {rc}")
+    xy = np.zeros((n.value, 2))
+    lib().svsdf_mesh_outline(_p(V), len(V), F.ctypes.data_as(ip), len(F), float(z0), _p(xy), n.value, C.byref(n), C.byref(loops))
+    return xy, loops.value
+
+
+def mesh_outline_obj(path, z0=0.0):
+    """Same from a Wavefront .obj file (svsdf_mesh_outline_obj)."""
+    n, loops = C.c_size_t(), C.c_int()
+    rc = lib().svsdf_mesh_outline_obj(str(path).encode(), float(z0), None, 0, C.byref(n), C.byref(loops))
+    if rc:
+        raise SvsdfError(f"svsdf_mesh_outline_obj({path}) failed: {rc}")
+    xy = np.zeros((n.value, 2))
+    lib().svsdf_mesh_outline_obj(str(path).encode(), float(z0), _p(xy), n.value, C.byref(n), C.byref(loops))
+    return xy, loops.value
 
 
 def forward_T(tau):
@@ -326,6 +356,8 @@ class SvsdfContext:
             cfg.n_devices = len(devices)
             for k, d in enumerate(devices):
                 cfg.devices[k] = int(d)
+        elif devices is not None and len(devices) == 1:                                    # a list of one: that device
+            cfg.device = int(devices[0])
         cfg.combine = int(combine)
         self._poly = None
         if polygon is not None:

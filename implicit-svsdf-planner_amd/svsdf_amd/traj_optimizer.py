@@ -11,9 +11,11 @@ The compute runs in libsvsdf_hip.so (gfx950); this class only marshals arguments
 torch.distributed initialised (one process per GPU) the query points are sharded over the ranks
 and the (19N+1)-double partial is summed with one all-reduce (RCCL on GPU ranks).
 """
+import os
+
 import numpy as np
 
-from .binding import SvsdfContext, SvsdfError, shape_id_from_inputdata, SHAPES
+from .binding import SvsdfContext, SvsdfError, shape_id_from_inputdata, SHAPES, mesh_outline_obj
 
 
 def _dist():
@@ -36,6 +38,7 @@ class TrajOptimizer:
         self.inputdata = "shapes/star.obj"
         self.poly_params = (0.0, 0.0, 0.0)
         self.polygon = None
+        self.package_path = ""         # what ros::package::getPath("plan_manager") returns (Shape.hpp:283)
         self.parallel_points = np.zeros((0, 3))
         self.parallel_points_num = 0
         self.cost_pos = 0.0
@@ -61,6 +64,7 @@ class TrajOptimizer:
         self.inputdata = config.get("inputdata", self.inputdata)
         self.poly_params = tuple(config.get("poly_params", self.poly_params))
         self.polygon = config.get("polygon", self.polygon)
+        self.package_path = config.get("package_path", self.package_path)
         self.device = int(config.get("device", self.device))
         self.devices = config.get("devices", self.devices)
         self.combine = int(config.get("combine", self.combine))
@@ -87,10 +91,17 @@ class TrajOptimizer:
     def _context(self):
         if self._ctx is None:
             sid = shape_id_from_inputdata(self.inputdata) if self.polygon is None else SHAPES.index("Polygon")
+            polygon = self.polygon
+            if sid == SHAPES.index("Polygon") and polygon is None:
+                # an .obj the shape registry does not know (BASELINE config 5): its z = 0 outline; unreadable -> the
+                # reference's hard-coded rectangle (sw_manager.hpp:363-369), which the library substitutes itself
+                path = os.path.join(self.package_path, self.inputdata) if self.package_path else self.inputdata
+                if os.path.exists(path):
+                    polygon, _ = mesh_outline_obj(path)
             dist = _dist()
             rank, ws = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
             self._ctx = SvsdfContext(shape=sid, safety_hor=self.safety_hor, weight_p=self.weight_p,
-                                     rho=self.rho, poly_params=self.poly_params, polygon=self.polygon,
+                                     rho=self.rho, poly_params=self.poly_params, polygon=polygon,
                                      head_state=self.initState, tail_state=self.finalState,
                                      device=self.device, rank=rank, world_size=ws,
                                      devices=self.devices, combine=self.combine)

@@ -7,6 +7,9 @@ around the waypoints, mirroring src/plan_manager/src/plan_manager.cpp:156-173 wi
 kernel_size * occupancy_resolution / 3) or "map" (uniform over the demo map extent).
 Seed 20240807, numpy PCG64 (identical numpy on the build and GPU boxes).
 """
+import json
+import os
+
 import numpy as np
 
 SEED = 20240807
@@ -31,22 +34,49 @@ INITTIME = 2.5
 OCC_RES = 1.0
 MAP_EXTENT = ((0.0, 30.5), (0.0, 75.0))  # bounds of src/plan_manager/pcds/map_*.pcd
 
-# BASELINE.json configs (C5 substitutes the star outline polygon: SURVEY.md §0-5 / §8(c))
+# BASELINE.json configs.  C5 ("arbitrary .obj mesh, no analytic shape SDF"): the reference's own mesh of the star
+# (src/plan_manager/shapes/star.obj, 152 vertices / 300 triangles, committed as data in tests/golden/reference_assets.json)
+# -> its z = 0 outline (77 vertices, svsdf_mesh_outline) -> the generic Polygon shape.
 CONFIGS = {
     "C1": dict(shape="star", N=8, P=10_000),
     "C2": dict(shape="star", N=16, P=100_000),
     "C3": dict(shape="sdHorseshoe", N=32, P=1_000_000),
     "C4": dict(shape="sdHeart", N=32, P=4_000_000),
-    "C5": dict(shape="Polygon", N=16, P=1_000_000, scenario="star"),
+    "C5": dict(shape="Polygon", N=16, P=1_000_000, scenario="star", mesh="star"),
     # the workload BASELINE.json's north_star target is quoted on: "1M-query-point / 16-segment MINCO
     # cost+grad evaluation at 1 GPU" with the demo shape of configs[0..1]
     "NS": dict(shape="star", N=16, P=1_000_000),
 }
 
 
+MESH_NAMES = ["sdArc", "sdCutDisk", "sdHeart", "sdHorseshoe", "sdOrientedVesica", "sdPie", "sdPie2", "sdRhombus",
+              "sdRoundedCross", "sdRoundedX", "sdTunnel", "sdUnevenCapsule", "star"]   # src/plan_manager/shapes/*.obj
+_ASSETS = None
+
+
+def reference_mesh(name):
+    """(V (nv, 3), F (nf, 3) zero-based) of the reference's shapes/<name>.obj, from the committed data fixture
+    (tests/golden/reference_assets.json, written by tests/golden/make_fixtures.py)."""
+    global _ASSETS
+    if _ASSETS is None:
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        _ASSETS = json.load(open(os.path.join(root, "tests", "golden", "reference_assets.json")))
+    return np.array(_ASSETS["shapes"][name], dtype=np.float64), np.array(_ASSETS["mesh_faces"][name], dtype=np.int32)
+
+
+def mesh_outline(name, z0=0.0):
+    """z = z0 outline of the reference mesh `name` through the product's svsdf_mesh_outline (host C++)."""
+    from . import binding
+    V, F = reference_mesh(name)
+    xy, loops = binding.mesh_outline(V, F, z0)
+    if loops != 1:
+        raise ValueError(f"{name}: {loops} closed loops in the z = {z0} section")
+    return xy
+
+
 def star_outline():
-    """10-vertex outline of the reference's `star` (r = 2.8, rf = 0.6; SHP:565-566) used as the
-    generic Polygon of config C5."""
+    """10-vertex outline of the reference's analytic `star` (r = 2.8, rf = 0.6; SHP:565-566): a small hand-made
+    Polygon for unit tests (config C5 uses the 77-vertex outline of the star MESH, mesh_outline("star"))."""
     r, rf = 2.8, 0.6
     # iq's sdStar5: outer tips at radius r, inner vertices where the two mirrored edges meet
     k1 = np.array([0.809016994375, -0.587785252292])
@@ -132,7 +162,7 @@ def make(config="C2", P=None, N=None, dist="corridor", seed=SEED, minco=None):
     else:
         raise ValueError(dist)
     w = dict(name=config if isinstance(config, str) else "custom", shape=shape, N=N, P=P, dist=dist,
-             polygon=star_outline() if shape == "Polygon" else None,
+             polygon=(mesh_outline(cfg["mesh"]) if cfg.get("mesh") else star_outline()) if shape == "Polygon" else None,
              safety_hor=sc["safety_hor"], weight_p=WEIGHT_P, rho=RHO, poly_params=sc["poly_params"],
              head_state=hs, tail_state=ts, q=q, T=T, points=pts)
     if minco is not None:

@@ -51,7 +51,7 @@ enum svsdf_shape_id {
 };
 
 #define SVSDF_MAX_PIECES 64        /* MINCO pieces per trajectory handled on the device */
-#define SVSDF_MAX_POLY_VERTS 256   /* Polygon outline vertices */
+#define SVSDF_MAX_POLY_VERTS 4096  /* Polygon outline vertices (the z = 0 outlines of the reference meshes have 77 ... 754) */
 #define SVSDF_MAX_DEVICES 8        /* GPUs one context can drive (one xGMI node) */
 
 /* Error codes (0 = ok).  HIP runtime errors are returned as SVSDF_ERR_HIP_BASE + hipError_t. */
@@ -77,7 +77,9 @@ typedef struct svsdf_config {
   double tail_state[9];      /* finalState 3x3 col-major                               BEO:50 */
   int device;                /* HIP device ordinal; -1 = current device */
   int polygon_nverts;        /* Polygon only: outline vertices (0 -> the 12 x 0.2 fallback  */
-  const double *polygon_xy;  /*   rectangle of SWM:363-369); xy interleaved, copied         */
+  const double *polygon_xy;  /*   rectangle of SWM:363-369); xy interleaved, copied.  For a mesh
+                                (conf.inputdata = an .obj the shape registry does not know) pass
+                                the outline svsdf_mesh_outline_obj() returns */
   int rank, world_size;      /* point sharding: this context keeps points k with
                                 (sorted index k) % world_size == rank.  1 process per GPU. */
   int flags;                 /* SVSDF_FLAG_* */
@@ -275,6 +277,21 @@ int svsdf_map_gather(const svsdf_map *map, const double *centres_xyz, size_t nce
                      double *out_xyz, size_t capacity, size_t *count);
 /* ASCII PCD v0.7, FIELDS x y z (src/plan_manager/pcds/map_*.pcd); xyz may be NULL to query n. */
 int svsdf_pcd_read_ascii(const char *path, float *xyz, size_t capacity, size_t *n);
+
+/* ---- mesh shapes (host; BASELINE config 5: "arbitrary .obj mesh, no analytic shape SDF") ------------------------ */
+/* The reference loads conf.inputdata with igl::read_triangle_mesh (src/utils/include/utils/Shape.hpp:281-313) and,
+ * when the file's stem is not in its shape registry, plans with the generic Polygon shape over an outline
+ * (sw_manager.hpp:350-372; the outline is hard-coded there).  Every query of the planar planner has z = 0
+ * (BEO:790-791), so the part of a mesh it can see is the cross-section z = z0 = 0: these two entry points return that
+ * outline (the longest closed loop; crossing points of the straddling triangles, chained through shared mesh edges) as
+ * the xy-interleaved vertex list svsdf_config::polygon_xy takes.  xy_out may be NULL to query *count; loops (may be
+ * NULL) receives the number of closed loops the section has (1 for one solid).
+ * V: nv x 3 doubles, F: nf x 3 zero-based vertex indices.  The .obj reader takes `v` / `f` records (1-based or negative
+ * indices, a/b/c forms, polygons fanned into triangles). */
+int svsdf_mesh_outline(const double *V, size_t nv, const int *F, size_t nf, double z0, double *xy_out,
+                       size_t capacity_verts, size_t *count, int *loops);
+int svsdf_mesh_outline_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *count,
+                           int *loops);
 
 /* ---- host-side MINCO helpers (MNC:397-655) ------------------------------------------------------- */
 /* waypoints inPs: 3 x (N-1) col-major; out coeffs (6N) x 3 col-major. */

@@ -43,10 +43,12 @@ class TrajOptimizerHip {
   int threads_num = 30;  // kept for source compatibility; the GPU path ignores it
   std::string inputdata = "shapes/star.obj";
   double poly_params[3] = {0.0, 0.0, 0.0};
-  std::vector<double> polygon_xy;  // optional outline for the Polygon fallback
+  std::string package_path;        // what ros::package::getPath("plan_manager") returns (Shape.hpp:283): prefix of inputdata
+  std::vector<double> polygon_xy;  // optional outline for the Polygon fallback; empty + an inputdata stem the shape
+                                   // registry does not know -> the z = 0 outline of that .obj mesh (BASELINE config 5)
   int device = -1;
   int rank = 0, world_size = 1;
-  std::vector<int> devices;        // >= 2 entries: in-process multi-GPU (svsdf_config::n_devices / devices)
+  std::vector<int> devices;        // >= 2 entries: in-process multi-GPU (svsdf_config::n_devices / devices); 1 entry: that device
   int combine = SVSDF_COMBINE_AUTO;
 
   // --- optimisation state (BEO:44-60) ---
@@ -76,7 +78,8 @@ class TrajOptimizerHip {
     // survives successive optimisations; only the boundary states change
     if (ctx_ && svsdf_set_conditions(ctx_, initState, finalState) != SVSDF_OK) { svsdf_destroy(ctx_); ctx_ = nullptr; }
   }
-  // after changing a Config-derived member (shape, weights, devices): rebuild the context on next use
+  // Config-derived members (shape, weights, devices ...) may be edited between optimisations like the reference's public
+  // members: context() compares them with what the live context was built from and rebuilds it on a mismatch.
   void resetContext() { svsdf_destroy(ctx_); ctx_ = nullptr; }
 
   // static double costFunctionLmbmParallel(void *ptr, const double *x, double *g, const int n)
@@ -139,23 +142,38 @@ class TrajOptimizerHip {
 #endif
 
   svsdf_ctx *context() {
+    const std::string key = config_key();
+    if (ctx_ && key != built_key_) resetContext();
     if (!ctx_) {
       svsdf_config cfg;
       svsdf_config_default(&cfg);
       cfg.shape_id = polygon_xy.empty() ? svsdf_shape_id_from_inputdata(inputdata.c_str()) : (int)SVSDF_SHAPE_Polygon;
+      std::vector<double> outline = polygon_xy;
+      if (cfg.shape_id == SVSDF_SHAPE_Polygon && outline.empty()) {
+        // an .obj the shape registry does not know: its z = 0 outline (the reference reads the same file with
+        // igl::read_triangle_mesh, Shape.hpp:281-284); unreadable -> the reference's hard-coded rectangle (SWM:363-369)
+        const std::string path = package_path.empty() ? inputdata : package_path + "/" + inputdata;
+        std::size_t n = 0;
+        if (svsdf_mesh_outline_obj(path.c_str(), 0.0, nullptr, 0, &n, nullptr) == SVSDF_OK && n >= 3) {
+          outline.resize(2 * n);
+          if (svsdf_mesh_outline_obj(path.c_str(), 0.0, outline.data(), n, &n, nullptr) != SVSDF_OK) outline.clear();
+        }
+      }
       std::memcpy(cfg.poly_params, poly_params, sizeof(poly_params));
       cfg.safety_hor = safety_hor; cfg.weight_p = weight_p; cfg.rho = rho;
       std::memcpy(cfg.head_state, initState, sizeof(initState));
       std::memcpy(cfg.tail_state, finalState, sizeof(finalState));
       cfg.device = device; cfg.rank = rank; cfg.world_size = world_size;
       cfg.combine = combine;
-      if (devices.size() >= 2 && devices.size() <= SVSDF_MAX_DEVICES) {
+      if (devices.size() == 1 && combine != SVSDF_COMBINE_RCCL) cfg.device = devices[0];
+      else if (!devices.empty() && devices.size() <= SVSDF_MAX_DEVICES) {
         cfg.n_devices = (int)devices.size();
         for (std::size_t k = 0; k < devices.size(); ++k) cfg.devices[k] = devices[k];
       }
-      cfg.polygon_nverts = (int)(polygon_xy.size() / 2);
-      cfg.polygon_xy = polygon_xy.empty() ? nullptr : polygon_xy.data();
+      cfg.polygon_nverts = (int)(outline.size() / 2);
+      cfg.polygon_xy = outline.empty() ? nullptr : outline.data();
       ctx_ = svsdf_create(&cfg);
+      built_key_ = key;
       points_dirty_ = true;
     }
     if (ctx_ && points_dirty_) {
@@ -166,6 +184,19 @@ class TrajOptimizerHip {
   }
 
  private:
+  // everything svsdf_create reads except the boundary states (those go through svsdf_set_conditions)
+  std::string config_key() const {
+    std::string k = inputdata + "|" + package_path + "|";
+    auto add = [&k](const void *p, std::size_t n) { k.append(static_cast<const char *>(p), n); };
+    add(&rho, sizeof rho); add(&weight_p, sizeof weight_p); add(&safety_hor, sizeof safety_hor);
+    add(poly_params, sizeof poly_params); add(&device, sizeof device); add(&rank, sizeof rank);
+    add(&world_size, sizeof world_size); add(&combine, sizeof combine);
+    if (!devices.empty()) add(devices.data(), devices.size() * sizeof(int));
+    k += "|";
+    if (!polygon_xy.empty()) add(polygon_xy.data(), polygon_xy.size() * sizeof(double));
+    return k;
+  }
+  std::string built_key_;
   svsdf_ctx *ctx_ = nullptr;
   bool points_dirty_ = true;
 };

@@ -54,6 +54,8 @@ def lib():
     L.orc_sdf_at_time.restype = C.c_double
     L.orc_sdf_at_time.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
     L.orc_sdf_swept.restype = C.c_double
+    L.orc_shape_eval_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp]
+    L.orc_shape_eval_batch.restype = None
     L.orc_sdf_swept.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp, _dp]
     L.orc_true_sdf.restype = C.c_double
     L.orc_true_sdf.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp, _dp]
@@ -139,6 +141,14 @@ class Oracle:
 
     def sdf_at_time(self, px, py, t):
         return self.L.orc_sdf_at_time(self.ctx, px, py, t)
+
+    def shape_eval(self, xy, grad=False):
+        """Raw body-frame getonlySDF (and getonlyGrad1) of this oracle's shape at (P, 2) points."""
+        xy = _f64(xy).reshape(-1, 2)
+        sdf = np.zeros(len(xy))
+        g = np.zeros((len(xy), 2)) if grad else None
+        self.L.orc_shape_eval_batch(self.ctx, _p(xy), len(xy), _p(sdf), _p(g))
+        return (sdf, g) if grad else sdf
 
     def sdf_swept(self, px, py):
         t = C.c_double(0.0)

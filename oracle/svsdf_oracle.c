@@ -599,6 +599,15 @@ double orc_sdf_at_time(orc_ctx *ctx, double px, double py, double t) {
   return sdf_at_time(ctx, px, py, t);
 }
 
+/* Batch of raw body-frame shape evaluations: getonlySDF(pos_rel) and getonlyGrad1(pos_rel) of the context's shape
+ * (no trajectory involved); sdf_out / grad_out (2 per point) may be NULL.  Test convenience only. */
+void orc_shape_eval_batch(orc_ctx *ctx, const double *xy, size_t P, double *sdf_out, double *grad_out) {
+  for (size_t i = 0; i < P; ++i) {
+    if (sdf_out) sdf_out[i] = orc_shape_sdf(&ctx->shape, xy[2 * i], xy[2 * i + 1]);
+    if (grad_out) orc_shape_grad(&ctx->shape, xy[2 * i], xy[2 * i + 1], grad_out + 2 * i);
+  }
+}
+
 /* getGradPrelAtTimeStamp<false> SWM:779-788 */
 static inline void grad_prel_at_time(const orc_ctx *ctx, double px, double py, double t,
                                      double g[2]) {

@@ -57,7 +57,7 @@ enum {
   ORC_SHAPE_COUNT = 17
 };
 
-#define ORC_MAX_POLY_VERTS 256
+#define ORC_MAX_POLY_VERTS 4096
 
 typedef struct orc_shape {
   int id;
@@ -111,6 +111,7 @@ double orc_traj_duration(const orc_ctx *ctx);
 void orc_traj_pos(const orc_ctx *ctx, double t, double out[3]);   /* TRJ:518-522 */
 void orc_traj_vel(const orc_ctx *ctx, double t, double out[3]);   /* TRJ:524-528 */
 double orc_sdf_at_time(orc_ctx *ctx, double px, double py, double t); /* SWM:741-750 */
+void orc_shape_eval_batch(orc_ctx *ctx, const double *xy, size_t P, double *sdf_out, double *grad_out);
 
 /* getSDFofSweptVolume<false,true> (SWM:844-866): returns sdf*, writes t* and grad. */
 double orc_sdf_swept(orc_ctx *ctx, double px, double py, double *t_star, double grad[3]);

@@ -2,7 +2,9 @@
 /root/reference does not exist on the GPU box).  Output: tests/golden/reference_assets.json
 
   * shapes/<name>.obj        -> vertex lists (the reference's own meshes of each analytic shape;
-                                every vertex lies on/inside the zero level set of that shape's SDF)
+                                every vertex lies on/inside the zero level set of that shape's SDF) and
+                                triangle lists ("mesh_faces", zero-based): the 13 meshes are the inputs of
+                                BASELINE config 5 (arbitrary .obj mesh -> z = 0 outline -> Polygon SDF)
   * pcds/map_<name>.pcd      -> obstacle point clouds (ASCII PCD v0.7, FIELDS x y z)
   * pcds/trajectory_<name>.txt, config/<name>.yaml -> start/end poses and the hot-path constants
 
@@ -19,6 +21,15 @@ KEYS = ["safety_hor", "weight_p", "rho", "inittime", "kernel_size", "occupancy_r
 
 def read_obj(path):
     return [[round(float(v), 6) for v in l.split()[1:4]] for l in open(path) if l.startswith("v ")]
+
+
+def read_obj_faces(path):
+    out = []
+    for l in open(path):
+        if l.startswith("f "):
+            idx = [int(t.split("/")[0]) - 1 for t in l.split()[1:]]
+            out += [[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)]
+    return out
 
 
 def read_pcd(path):
@@ -44,9 +55,10 @@ def read_yaml_consts(path):
 def main():
     names = sorted(f[:-5] for f in os.listdir(os.path.join(REF, "config")) if f.endswith(".yaml"))
     assets = {"source": "ZJU-FAST-Lab/Implicit-SVSDF-Planner @ 2024_08_07, src/plan_manager/{shapes,pcds,config}",
-              "shapes": {}, "scenarios": {}, "maps": {}}
+              "shapes": {}, "mesh_faces": {}, "scenarios": {}, "maps": {}}
     for n in names:
         assets["shapes"][n] = read_obj(os.path.join(REF, "shapes", n + ".obj"))
+        assets["mesh_faces"][n] = read_obj_faces(os.path.join(REF, "shapes", n + ".obj"))
         sc = read_yaml_consts(os.path.join(REF, "config", n + ".yaml"))
         se = open(os.path.join(REF, "pcds", "trajectory_%s.txt" % n)).read().split("\n")
         sc["start"] = [float(v) for v in se[0].split()[1:4]]

@@ -1,0 +1,93 @@
+"""BASELINE config 5 on the GPU: "arbitrary .obj mesh ... (no analytic shape SDF)".
+
+Every mesh the reference ships (src/plan_manager/shapes/*.obj; data fixture tests/golden/reference_assets.json) goes
+mesh -> z = 0 outline (svsdf_mesh_outline, host C++) -> generic Polygon shape (Polygon::getonlySDF, Shape.hpp:1448-1476)
+-> the whole HIP pipeline through the C ABI, against the CPU oracle's plain loop over all edges:
+  * reduced cost / gradients at the north-star gates (cost 1e-7, gradient 1e-5) against the oracle of record;
+  * per-point SVSDF, t* and gradient direction BIT FOR BIT against the oracle in device-trig mode -- the candidate lists
+    (grid cells / slabs) the kernels use instead of the loop over all 77 ... 754 edges change no bit anywhere.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+NT = os.cpu_count() or 1
+MESHES = ["sdArc", "sdCutDisk", "sdHeart", "sdHorseshoe", "sdOrientedVesica", "sdPie", "sdPie2", "sdRhombus",
+          "sdRoundedCross", "sdRoundedX", "sdTunnel", "sdUnevenCapsule", "star"]
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+def _mk(name, P, N=8, dist="corridor"):
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make(dict(shape="Polygon", N=N, P=P, scenario="star", mesh=name), dist=dist, minco=svsdf_amd.minco_coeffs)
+    kw = dict(safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"], polygon=w["polygon"],
+              head_state=w["head_state"], tail_state=w["tail_state"])
+    ctx = svsdf_amd.SvsdfContext(shape="Polygon", device=0, **kw)
+    ctx.set_points(w["points"])
+    o = orc.Oracle("Polygon", **kw)
+    o.set_traj(w["coeffs"], w["T"])
+    return w, ctx, o
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_mesh_outline_shape_matches_oracle(built, name):
+    big = name in ("sdArc", "sdRoundedCross")          # 754 / 614 edges: the oracle's loop is what takes the time
+    w, ctx, o = _mk(name, 400 if big else 900)
+    assert ctx.shape_bound()[1] <= ctx.shape_bound()[0]
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
+    assert ocost > 0
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost), (cost, ocost)
+    assert _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5, (_rel(gC, ogC), _rel(gT, ogT))
+    o.set_trig_mode(1)
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    osdf, ots, og = o.query(w["points"], nthreads=NT)
+    assert (osdf <= 0).sum() > 20                       # interior points: the GSIP loop ran
+    assert np.array_equal(ts, ots) and np.array_equal(sdf, osdf) and np.array_equal(g, og), name
+
+
+def test_c5_is_the_star_mesh_outline(built):
+    """CONFIGS["C5"]: the 77-vertex z = 0 outline of the reference's star.obj, 16 pieces (BASELINE configs[4])."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make("C5", P=64, minco=svsdf_amd.minco_coeffs)
+    assert w["shape"] == "Polygon" and w["polygon"].shape == (77, 2) and len(w["T"]) == 16
+    V, F = workload.reference_mesh("star")
+    assert V.shape == (152, 3) and F.shape == (300, 3)
+    # the outline hugs the analytic star the mesh was made from (r = 2.8): every vertex within 6 cm of its zero set
+    sd = orc.Oracle("star").shape_eval(w["polygon"])
+    assert np.abs(sd).max() < 0.06
+
+
+def test_c5_map_distribution_and_far_points(built):
+    """Map-uniform cloud (points up to ~70 m from the robot: far outside both candidate grids -> the full-loop path of
+    the Polygon evaluation, and the exact cull) against the oracle."""
+    w, ctx, o = _mk("star", 3000, N=16, dist="map")
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    st = ctx.stats()
+    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
+    assert st["culled_points"] > 0.3 * 3000
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost) and _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5
+    o.set_trig_mode(1)
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    osdf, ots, og = o.query(w["points"], nthreads=NT)
+    assert np.array_equal(ts, ots) and np.array_equal(sdf, osdf) and np.array_equal(g, og)
+
+
+def test_polygon_vertex_limit(built):
+    import svsdf_amd
+    ang = np.linspace(0, 2 * np.pi, 4096, endpoint=False)
+    ok = svsdf_amd.SvsdfContext(shape="Polygon", device=0, polygon=np.column_stack([2 * np.cos(ang), 2 * np.sin(ang)]))
+    assert abs(ok.shape_bound()[0] - 2.0) < 1e-3
+    ok.close()
+    ang = np.linspace(0, 2 * np.pi, 4097, endpoint=False)
+    with pytest.raises(svsdf_amd.SvsdfError):
+        svsdf_amd.SvsdfContext(shape="Polygon", device=0, polygon=np.column_stack([2 * np.cos(ang), 2 * np.sin(ang)]))

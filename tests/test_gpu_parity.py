@@ -173,7 +173,7 @@ def _budget_points(evals_per_point, seconds=4.0):
 
 
 @pytest.mark.parametrize("config,full,evals_pp", [("C2", 100000, 6500), ("C3", 1000000, 11000), ("C4", 500000, 11000),
-                                                  ("C5", 1000000, 20000)])
+                                                  ("C5", 1000000, 90000)])
 def test_baseline_sizes_match_oracle(built, config, full, evals_pp):
     """The BASELINE.json workloads at the largest size the oracle finishes in a few seconds on this host (all of
     C2's 100 k points on a 256-core box): per-point SVSDF and t*, interior count, reduced cost and gradients.
@@ -215,32 +215,56 @@ def test_map_distribution_matches_oracle(built, config, evals_pp):
           f"{abs(cost - ocost) / abs(ocost):.2e}, gradC rel {_rel(gC, ogC):.2e}, gradT rel {_rel(gT, ogT):.2e}")
 
 
-def test_differential_fuzz(built):
-    """tools/fuzz_parity.py: 60 random (shape, shape offset, 1-6 piece trajectory with generic durations, safety margin,
-    400 points) cases, HIP vs the oracle of record (glibc trig, reference piece location).  Gates: cost 1e-7, gradient
-    1e-5 (north_star).  Round 1 needed 1e-4 here: its single-subtraction piece-local time is <= i ulp(t) away from the
-    reference's chain of subtractions, and the flat stretches of SDF(t) at resting end poses amplify that (300-case
-    campaign: 84 cases outside the gates, gradC up to 4.9e-5, 17 % basin flips).  With the reference's chain (the
-    library's default for generic durations) the same campaign has 13 cases outside -- all by basin flips > 1 % -- and
-    gradC <= 1.03e-5: what is left is libm (device sin/cos/atan2 vs glibc), and it vanishes to the last bit when the
-    oracle uses the device library's trig (test_bit_identical_when_oracle_uses_device_trig, fuzz with
-    FUZZ_DEVICE_TRIG=1: 300 / 300 cases identical)."""
+def _source_seed():
+    """A fuzz seed nobody picked: derived from the commit when .git is there, else (the GPU box gets a snapshot without
+    .git) from a hash of the product sources -- it moves with every change of the kernels."""
+    import hashlib, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        h = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           check=True).stdout.decode().strip()
+        if h:
+            return int(h[:8], 16) % 1000003
+    except Exception:
+        pass
+    m = hashlib.sha256()
+    src = os.path.join(root, "implicit-svsdf-planner_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        m.update(open(os.path.join(src, f), "rb").read())
+    return int(m.hexdigest()[:8], 16) % 1000003
+
+
+def _fuzz(cases, seed, **env):
     import ast, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FUZZ_DEGENERATE="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "7"], env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(cases), str(seed)],
+                         env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode()
     last = out.strip().splitlines()[-1]
-    worst = ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1])
-    assert "HIP error" not in out, out[-2000:]
-    assert worst["cost"] <= 1e-7 and worst["gC"] <= 1e-5 and worst["gT"] <= 1e-5, last
-    # the round-1 arithmetic (forced) on the same cases: inside the old, looser gate only
-    env["FUZZ_PIECE_TIME"] = "fast"
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "7"], env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode()
-    last = out.strip().splitlines()[-1]
-    worst_fast = ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1])
-    assert worst_fast["cost"] <= 1e-7 and worst_fast["gC"] <= 1e-4, last
+    return ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1]), out
+
+
+def test_differential_fuzz(built):
+    """tools/fuzz_parity.py: random (shape incl. mesh outlines, shape offset, 1-6 piece trajectory with generic
+    durations, safety margin, 400 points) cases WITH the degenerate points (exactly on waypoints = on the zero level set
+    of some shapes at a rest pose), HIP vs the oracle of record (glibc trig, reference piece location), for three seeds:
+    two fixed ones and one nobody chose (derived from the commit / the source tree).  Gates: cost 1e-7, gradient 1e-5
+    (north_star), basin flips 1 %.  A case outside them is admitted ONLY when the oracle against ITSELF -- glibc's
+    sin/cos/atan2 vs the ROCm device library's, the one arithmetic difference between the HIP path and the oracle of
+    record -- shows the same deviation to 1e-3 relative on every violated metric (plateaus of SDF(t): resting end poses,
+    turn-on-the-spot trajectories; the reference's own result would move with the libm build there,
+    tests/test_plateau_sensitivity.py).  Everything else fails the test."""
+    seeds = [7, 20240807, _source_seed()]
+    total_explained = 0
+    for seed in seeds:
+        worst, out = _fuzz(40, seed, FUZZ_DEGENERATE="1")
+        assert "HIP error" not in out, out[-2000:]
+        print(f"seed {seed}: worst {worst}")
+        assert worst["unexplained"] == 0, out[-4000:]
+        total_explained += worst["libm_explained"]
+    assert total_explained <= 0.1 * 40 * len(seeds)   # plateaus are rare, not the rule
+    # the round-1 arithmetic (forced) on the first seed: inside the old, looser gate only
+    worst_fast, out = _fuzz(40, 7, FUZZ_DEGENERATE="0", FUZZ_PIECE_TIME="fast")
+    assert worst_fast["cost"] <= 1e-7 and worst_fast["gC"] <= 1e-4, out[-2000:]
 
 
 @pytest.mark.parametrize("config,P", [("C1", 6000), ("C2", 6000), ("C3", 4000), ("C4", 4000), ("C5", 3000)])
@@ -266,19 +290,13 @@ def test_bit_identical_when_oracle_uses_device_trig(built, config, P):
 
 
 def test_differential_fuzz_bit_identical_in_device_arithmetic_mode(built):
-    """Same random cases as test_differential_fuzz (all 17 shapes, shape offsets, 1-6 unequal pieces), this time WITH
-    the degenerate points (exactly on waypoints = on the zero level set of some shapes at a rest pose) and with the
-    oracle in device-arithmetic mode: not one of the per-point (t*, SVSDF) values may differ in any bit, and cost /
-    gradients agree to summation order (1e-12)."""
-    import ast, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FUZZ_DEGENERATE="1", FUZZ_DEVICE_TRIG="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "11"], env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode()
-    last = out.strip().splitlines()[-1]
-    worst = ast.literal_eval(last[last.index("worst") + 6:last.rindex("}") + 1])
-    assert worst["not_identical"] == 0, out[-3000:]
-    assert worst["cost"] <= 1e-12 and worst["gC"] <= 1e-12 and worst["gT"] <= 1e-12 and worst["flips"] == 0.0, last
+    """Same kind of random cases as test_differential_fuzz (all 17 shapes incl. mesh outlines, shape offsets, 1-6 unequal
+    pieces, degenerate points), with the oracle in device-arithmetic mode: not one of the per-point (t*, SVSDF) values
+    may differ in any bit, and cost / gradients agree to summation order (1e-12).  Two seeds, one of them nobody chose."""
+    for seed in (11, _source_seed() + 1):
+        worst, out = _fuzz(40, seed, FUZZ_DEGENERATE="1", FUZZ_DEVICE_TRIG="1")
+        assert worst["not_identical"] == 0, out[-3000:]
+        assert worst["cost"] <= 1e-12 and worst["gC"] <= 1e-12 and worst["gT"] <= 1e-12 and worst["flips"] == 0.0, out[-2000:]
 
 
 def test_limits(built):

@@ -1,5 +1,13 @@
 """Differential fuzzing (GPU box): random shapes / shape offsets / trajectories / points, HIP path vs the oracle.
-Prints every case outside the gates (cost 1e-7 rel, gradient 1e-5 rel) or with > 1 % basin flips."""
+Prints every case outside the gates (cost 1e-7 rel, gradient 1e-5 rel) or with > 1 % basin flips.
+
+A case outside the gates is then CLASSIFIED: the oracle is run a second time with the ROCm device library's sin / cos /
+atan2 in place of glibc's (orc.set_modes(1, 0): the ONLY arithmetic the HIP path does not share with the oracle of
+record) and its deviation from the oracle of record is measured with the same metrics.  If oracle-vs-oracle shows the
+same deviation as HIP-vs-oracle to 1e-3 relative on every violated metric, the case is `libm_explained` (a plateau of
+SDF(t): the reference's own result would change with the libm build, tests/test_plateau_sensitivity.py); anything else is
+`unexplained` and is what tests/test_gpu_parity.py::test_differential_fuzz fails on.
+usage: fuzz_parity.py [cases] [seed]   env FUZZ_DEGENERATE=0|1 (default 1), FUZZ_DEVICE_TRIG, FUZZ_PIECE_TIME"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "implicit-svsdf-planner_amd")]
@@ -10,7 +18,7 @@ NT = os.cpu_count() or 1
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
-worst = dict(cost=0.0, gC=0.0, gT=0.0, flips=0.0)
+worst = dict(cost=0.0, gC=0.0, gT=0.0, flips=0.0, libm_explained=0, unexplained=0, worst_unexplained_gC=0.0)
 t00 = time.time()
 for case in range(ncase):
     rng = np.random.default_rng(seed0 * 100003 + case)
@@ -18,10 +26,13 @@ for case in range(ncase):
     pp = (0.0, 0.0, 0.0) if rng.random() < 0.4 else (rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-180, 180))
     poly = None
     if shape == "Polygon":
-        k = int(rng.integers(3, 9))
-        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
-        rad = rng.uniform(0.8, 3.0, k)
-        poly = np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
+        if rng.random() < 0.5:    # the z = 0 outline of one of the reference's meshes (BASELINE config 5), 77 ... 754 vertices
+            poly = workload.mesh_outline(workload.MESH_NAMES[rng.integers(0, len(workload.MESH_NAMES))]) * rng.uniform(0.5, 1.2)
+        else:
+            k = int(rng.integers(3, 9))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            rad = rng.uniform(0.8, 3.0, k)
+            poly = np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
     N = int(rng.integers(1, 7))
     T = rng.uniform(0.3, 4.0, N)
     kind = rng.integers(0, 4)
@@ -74,7 +85,24 @@ for case in range(ncase):
     worst["flips"] = max(worst["flips"], flips)
     if rc > 1e-7 or rC > 1e-5 or rT > 1e-5 or flips > 0.01 or not np.isfinite(cost):
         bad += 1
+        verdict = "n/a"
+        if not devtrig and np.isfinite(cost):
+            # oracle vs oracle: glibc trig (of record) against the device library's trig, same metrics
+            o.set_modes(1, 0 if exact_time else 1)
+            c1, gT1, gC1, _, ts1, _ = o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True)
+            o.set_modes(0, 0)
+            d_c = abs(c1 - ocost) / max(abs(ocost), 1e-300) if ocost != 0 else abs(c1)
+            d_C, d_T = (rel(gC1, ogC), rel(gT1, ogT)) if ocost != 0 else (float(np.abs(gC1).max()), float(np.abs(gT1).max()))
+            d_f = float((np.abs(ts1 - ots) > 1e-6).mean())
+            same = lambda a, b: abs(a - b) <= 1e-3 * max(abs(b), 1e-300)
+            ok = ((rc <= 1e-7 or same(rc, d_c)) and (rC <= 1e-5 or same(rC, d_C)) and (rT <= 1e-5 or same(rT, d_T)) and
+                  (flips <= 0.01 or abs(flips - d_f) <= 1e-3 * max(d_f, 1e-300) + 0.5 / P))
+            verdict = "libm_explained" if ok else "UNEXPLAINED"
+            worst["libm_explained" if ok else "unexplained"] += 1
+            if not ok:
+                worst["worst_unexplained_gC"] = max(worst["worst_unexplained_gC"], rC)
+            verdict += f" (oracle glibc vs oracle device-trig: cost {d_c:.2e} gC {d_C:.2e} gT {d_T:.2e} flips {d_f:.3f})"
         print(f"CASE {case} seed {seed0} shape {shape} pp {np.round(pp, 3)} N {N} kind {kind} sh {sh:.3f}: cost {cost:.9g} vs {ocost:.9g} "
-              f"(rel {rc:.2e}) gC {rC:.2e} gT {rT:.2e} flips {flips:.3f} interior {int((osdf <= 0).sum())}", flush=True)
+              f"(rel {rc:.2e}) gC {rC:.2e} gT {rT:.2e} flips {flips:.3f} interior {int((osdf <= 0).sum())} -> {verdict}", flush=True)
     ctx.close()
 print(f"{ncase} cases, {bad} outside the gates, worst {worst}, {time.time() - t00:.1f} s")
