@@ -90,7 +90,7 @@ struct svsdf_ctx {
   hipStream_t bstream[kMaxBatches] = {};      // one stream per point batch
   hipEvent_t ev_prep = nullptr, ev_done[kMaxBatches] = {};
   ShapeParams sp{};
-  unsigned char *d_poly = nullptr;   // Polygon: one device blob [PolyAccel | edges | cell offsets | slab offsets | candidates | slab edges]
+  unsigned char *d_poly = nullptr;   // Polygon: one device blob [PolyAccel | edges | cell records | slab records | long lists]
   std::vector<double> poly_xy;       // Polygon: the outline as given (host copy)
   std::string err;
 
@@ -307,7 +307,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
                   double cull_thresh = std::numeric_limits<double>::infinity()) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
-  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N)) * sizeof(double);
+  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + poly_lds_doubles(ctx->sp.nverts, ctx->sp.edges_lds)) * sizeof(double);
   // Every block stages the pose table + chunk bounds + trajectory into LDS (13 KB at 16 pieces x 2.5 s, 24 KB at 32):
   // with one wave per block that caps the CU at 160 KB / lds waves -- 6 at C3, half of what the kernel's 141 VGPRs
   // allow (3 waves per SIMD) -- so the block grows until LDS no longer binds (measured at C3: 10.7 -> 9.2 ms).
@@ -330,7 +330,7 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;   // k_round MODE: cheap / full / lazy bound
   const bool scans = mode != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
-  const size_t lds = table_lds_doubles(ctx) * sizeof(double);
+  const size_t lds = (table_lds_doubles(ctx) + poly_lds_doubles(ctx->sp.nverts, ctx->sp.edges_lds)) * sizeof(double);
   // late iterations hold few points and are latency-bound: request every sample there, which
   // avoids supplementary iterations at no cost in time
   // the seed bound of the scanning modes is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
@@ -1410,6 +1410,8 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   sp.identity = (sp.tx == 0.0 && sp.ty == 0.0 && sp.r00 == 1.0 && sp.r01 == 0.0 && sp.r10 == 0.0 && sp.r11 == 1.0) ? 1 : 0;
   sp.nverts = 0;
   sp.accel = nullptr;
+  sp.edges = nullptr;
+  sp.edges_lds = 0;
   if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
     std::vector<double> &v = ctx->poly_xy;
     if (cfg->polygon_xy && cfg->polygon_nverts >= 3) {
@@ -1425,27 +1427,28 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     auto align = [](size_t o) { return (o + 63) & ~(size_t)63; };
     const size_t o_edges = align(sizeof(PolyAccel));
     const size_t o_cell = align(o_edges + pa.edges.size() * sizeof(PolyEdge));
-    const size_t o_slab = align(o_cell + pa.cell_off.size() * sizeof(unsigned));
-    const size_t o_cand = align(o_slab + pa.slab_off.size() * sizeof(unsigned));
-    const size_t o_sedg = align(o_cand + pa.cand.size() * sizeof(unsigned short));
-    const size_t total = align(o_sedg + pa.slab_edges.size() * sizeof(unsigned short));
+    const size_t o_slab = align(o_cell + pa.cells.size() * sizeof(PolyRec));
+    const size_t o_over = align(o_slab + pa.slabs.size() * sizeof(PolyRec));
+    const size_t total = align(o_over + pa.over.size() * sizeof(unsigned short));
     if (hipMalloc((void **)&ctx->d_poly, total) != hipSuccess) return bail("hipMalloc polygon failed");
     std::vector<unsigned char> blob(total, 0);
     pa.hdr.edges = reinterpret_cast<const PolyEdge *>(ctx->d_poly + o_edges);
-    pa.hdr.cell_off = reinterpret_cast<const unsigned *>(ctx->d_poly + o_cell);
-    pa.hdr.slab_off = reinterpret_cast<const unsigned *>(ctx->d_poly + o_slab);
-    pa.hdr.cand = reinterpret_cast<const unsigned short *>(ctx->d_poly + o_cand);
-    pa.hdr.slab_edges = reinterpret_cast<const unsigned short *>(ctx->d_poly + o_sedg);
+    pa.hdr.cells = reinterpret_cast<const PolyRec *>(ctx->d_poly + o_cell);
+    pa.hdr.slabs = reinterpret_cast<const PolyRec *>(ctx->d_poly + o_slab);
+    pa.hdr.over = reinterpret_cast<const unsigned short *>(ctx->d_poly + o_over);
     std::memcpy(blob.data(), &pa.hdr, sizeof(PolyAccel));
     std::memcpy(blob.data() + o_edges, pa.edges.data(), pa.edges.size() * sizeof(PolyEdge));
-    std::memcpy(blob.data() + o_cell, pa.cell_off.data(), pa.cell_off.size() * sizeof(unsigned));
-    std::memcpy(blob.data() + o_slab, pa.slab_off.data(), pa.slab_off.size() * sizeof(unsigned));
-    std::memcpy(blob.data() + o_cand, pa.cand.data(), pa.cand.size() * sizeof(unsigned short));
-    std::memcpy(blob.data() + o_sedg, pa.slab_edges.data(), pa.slab_edges.size() * sizeof(unsigned short));
+    std::memcpy(blob.data() + o_cell, pa.cells.data(), pa.cells.size() * sizeof(PolyRec));
+    std::memcpy(blob.data() + o_slab, pa.slabs.data(), pa.slabs.size() * sizeof(PolyRec));
+    if (!pa.over.empty()) std::memcpy(blob.data() + o_over, pa.over.data(), pa.over.size() * sizeof(unsigned short));
     if (hipMemcpy(ctx->d_poly, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess)
       return bail("hipMemcpy polygon failed");
     sp.nverts = (int)(v.size() / 2);
     sp.accel = reinterpret_cast<const PolyAccel *>(ctx->d_poly);
+    sp.edges = pa.hdr.edges;
+    // the solve / round kernels keep outlines of up to 512 edges (20 KB) in LDS next to the pose table
+    sp.edges_lds = (sp.nverts <= 512) ? 1 : 0;
+    if (const char *e = std::getenv("SVSDF_POLY_LDS")) sp.edges_lds = std::atoi(e) != 0 && sp.nverts <= 2048;
     ctx->cfg.polygon_nverts = sp.nverts;
   }
   ctx->G_env = 0;

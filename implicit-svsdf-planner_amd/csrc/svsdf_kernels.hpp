@@ -107,6 +107,20 @@ __device__ __forceinline__ TrajL stage_traj(const TrajDev *__restrict__ g, doubl
   return tr;
 }
 
+// Polygon: copy the outline's edges (5 doubles each) behind the other LDS tables of the block and point sp at the copy;
+// call before the block's __syncthreads.  lds_doubles(n) = 5 n when the host asked for it (sp.edges_lds), else 0.
+__host__ __device__ __forceinline__ size_t poly_lds_doubles(int nverts, int edges_lds) { return edges_lds ? 5 * (size_t)nverts : 0; }
+template <int SHAPE>
+__device__ __forceinline__ void stage_poly_edges(ShapeParams &sp, double *lds) {
+  if constexpr (SHAPE == kPolygon) {
+    if (sp.edges_lds) {
+      const double *src = reinterpret_cast<const double *>(sp.edges);
+      for (int i = threadIdx.x; i < 5 * sp.nverts; i += blockDim.x) lds[i] = src[i];
+      sp.edges = reinterpret_cast<const PolyEdge *>(lds);
+    }
+  }
+}
+
 // Trajectory::locatePieceIdx (TRJ:498-516) on cumulative start times: piece = first i with
 // t <= S[i+1] (clamped to N-1), local time = t - S[i].  `i` is a per-lane cache of the last piece.
 __device__ __forceinline__ int locate_piece(const TrajL &tr, double t, int i) {
@@ -764,6 +778,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
+  stage_poly_edges<SHAPE>(sp, solve_lds + 4 * (size_t)K + 4 * (size_t)nch + (size_t)traj_lds_doubles(trg->N));
   Pose *pose = reinterpret_cast<Pose *>(solve_lds);
   Chunk *chunks = reinterpret_cast<Chunk *>(solve_lds + 4 * (size_t)K);
   {
@@ -1294,6 +1309,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   const int nch = (K + kChunk - 1) / kChunk;
   Pose *pose = reinterpret_cast<Pose *>(round_lds);
   Chunk *chunks = reinterpret_cast<Chunk *>(round_lds + 4 * (size_t)K);
+  stage_poly_edges<SHAPE>(sp, round_lds + 4 * (size_t)K + 4 * (size_t)nch);
   {
     const double *src = reinterpret_cast<const double *>(pose_g);
     for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) round_lds[i] = src[i];

@@ -31,12 +31,18 @@
 
 namespace svsdf {
 
-struct PolyEdge { double sx, sy, ex, ey, vx, vy, vv, pad; };   // start, end, v = end - start, v.squaredNorm(): 64 B
+struct PolyEdge { double sx, sy, vx, vy, vv; };   // start, v = end - start, v.squaredNorm(); the end is the next edge's start
+
+// A candidate list in one 32-byte record of 16-bit words: [0] = count; count <= 15: [1 .. count] = the edges, ascending;
+// count > 15: [1] | [2] << 16 = offset of the list in `over`.  One 32-byte load gives a query its whole list in registers
+// (the evaluation walks it with shifts: no dependent load per edge).
+struct alignas(32) PolyRec { unsigned long long q[4]; };
+constexpr int kPolyInline = 15;
 
 struct PolyLevel {
   double x0, y0, inv_h;   // cell (ix, iy) = floor((x - x0) * inv_h), floor((y - y0) * inv_h)
   int nx, ny;
-  unsigned base;          // first entry of this level in cell_off (nx * ny + 1 entries)
+  unsigned base;          // first record of this level in `cells` (nx * ny records)
   int pad;
 };
 
@@ -44,15 +50,14 @@ struct PolyAccel {
   int n;                         // edges = vertices
   int nslab;
   const PolyEdge *edges;
-  const unsigned *cell_off;      // per level: offsets into cand
-  const unsigned short *cand;    // candidate edges of a cell, ascending
-  const unsigned *slab_off;      // nslab + 1 offsets into slab_edges
-  const unsigned short *slab_edges;
+  const PolyRec *cells;          // candidate edges per grid cell (both levels)
+  const PolyRec *slabs;          // candidate edges per parity slab
+  const unsigned short *over;    // lists longer than kPolyInline
   PolyLevel lv[2];               // 0 fine, 1 coarse
   double ymin, ymax, xmax, tol, slab_inv_h;
 };
 
-constexpr int kPolyMaxVerts = 4096;   // = SVSDF_MAX_POLY_VERTS (unsigned short candidate indices; host build time)
+constexpr int kPolyMaxVerts = 4096;   // = SVSDF_MAX_POLY_VERTS (16-bit edge indices; host build time)
 
 // isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
 // atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
@@ -94,16 +99,36 @@ __host__ __device__ __forceinline__ int poly_cell(const PolyLevel &lv, double x,
   return (int)fy * lv.nx + (int)fx;
 }
 
+// walk the candidate list of a record: f(edge index) in ascending order
+template <typename F>
+__host__ __device__ __forceinline__ void poly_for_each(const PolyRec &rec, const unsigned short *over, F &&f) {
+  unsigned long long q0 = rec.q[0], q1 = rec.q[1], q2 = rec.q[2], q3 = rec.q[3];
+  const unsigned cnt = (unsigned)(q0 & 0xffffull);
+  const bool inl = cnt <= (unsigned)kPolyInline;
+  const unsigned off = (unsigned)((q0 >> 16) & 0xffffffffull);
+  for (unsigned k = 0; k < cnt; ++k) {
+    unsigned idx;
+    if (inl) {   // next 16-bit word of the 256-bit record
+      q0 = (q0 >> 16) | (q1 << 48); q1 = (q1 >> 16) | (q2 << 48); q2 = (q2 >> 16) | (q3 << 48); q3 >>= 16;
+      idx = (unsigned)(q0 & 0xffffull);
+    } else {
+      idx = over[off + k];
+    }
+    f((int)idx);
+  }
+}
+
 // Polygon::getonlySDF (SHP:1448-1476).  CLOSEST: also the closest point the reference's loop ends with (first edge
 // among equal rooted distances; needed by the analytic gradient SHP:1505-1531) -- then the per-edge roots are taken
 // like the reference does; value only: min_i sqrt(d2_i) == sqrt(min_i d2_i) exactly (sqrt is correctly rounded and
-// monotone), one root per evaluation.
+// monotone), one root per evaluation.  `edges` = pa.edges or a copy of it (LDS).
 template <bool CLOSEST>
-__host__ __device__ inline double poly_sdf(const PolyAccel &pa, double x, double y, double *cminx, double *cminy) {
+__host__ __device__ inline double poly_sdf(const PolyAccel &pa, const PolyEdge *edges, double x, double y, double *cminx,
+                                           double *cminy) {
   double best = CLOSEST ? 1e9 : 1e300, mx = 0.0, my = 0.0;
   auto visit = [&](int i) {
     double cx, cy;
-    const double d2 = poly_edge_d2(pa.edges[i], x, y, cx, cy);
+    const double d2 = poly_edge_d2(edges[i], x, y, cx, cy);
     if constexpr (CLOSEST) {
       const double dis = sqrt(d2);
       if (dis < best) { best = dis; mx = cx; my = cy; }
@@ -114,21 +139,23 @@ __host__ __device__ inline double poly_sdf(const PolyAccel &pa, double x, double
   int cell = poly_cell(pa.lv[0], x, y);
   unsigned base = pa.lv[0].base;
   if (cell < 0) { cell = poly_cell(pa.lv[1], x, y); base = pa.lv[1].base; }
+  // the slab of the query's ray, when any edge can cross it
+  const bool ray = y >= pa.ymin - pa.tol && y <= pa.ymax + pa.tol && x <= pa.xmax + pa.tol;
+  const double fs = (y - pa.ymin) * pa.slab_inv_h;
+  const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
   if (cell >= 0) {
-    const unsigned k0 = pa.cell_off[base + (unsigned)cell], k1 = pa.cell_off[base + (unsigned)cell + 1u];
-    for (unsigned k = k0; k < k1; ++k) visit((int)pa.cand[k]);
+    poly_for_each(pa.cells[base + (unsigned)cell], pa.over, visit);
   } else {
     for (int i = 0; i < pa.n; ++i) visit(i);
   }
   int rs = 0;
-  if (y >= pa.ymin - pa.tol && y <= pa.ymax + pa.tol && x <= pa.xmax + pa.tol) {
-    const double fs = (y - pa.ymin) * pa.slab_inv_h;
-    const int s = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
-    const unsigned k0 = pa.slab_off[s], k1 = pa.slab_off[s + 1];
-    for (unsigned k = k0; k < k1; ++k) {
-      const PolyEdge &e = pa.edges[pa.slab_edges[k]];
-      if (poly_cross_ray(e.sx - x, e.sy - y, e.ex - x, e.ey - y)) rs++;
-    }
+  if (ray) {
+    const int n = pa.n;
+    poly_for_each(pa.slabs[slab], pa.over, [&](int i) {
+      const PolyEdge &e = edges[i];
+      const PolyEdge &nx = edges[(i + 1 == n) ? 0 : i + 1];   // end of edge i = start of the next edge
+      if (poly_cross_ray(e.sx - x, e.sy - y, nx.sx - x, nx.sy - y)) rs++;
+    });
   }
   double dis_min;
   if constexpr (CLOSEST) {
@@ -146,15 +173,16 @@ __host__ __device__ inline double poly_sdf(const PolyAccel &pa, double x, double
 // ------------------------------------------------------------------------------------------------------------------
 struct PolyAccelHost {
   std::vector<PolyEdge> edges;
-  std::vector<unsigned> cell_off;
-  std::vector<unsigned short> cand;
-  std::vector<unsigned> slab_off;
-  std::vector<unsigned short> slab_edges;
+  std::vector<PolyRec> cells, slabs;
+  std::vector<unsigned short> over;
   PolyAccel hdr{};   // pointers unset
+  // statistics
+  size_t cand_total = 0, cand_max = 0, slab_max = 0;
 };
 
 namespace poly_detail {
-inline double seg_point_dist(const PolyEdge &e, double x, double y) {
+struct Seg { double sx, sy, ex, ey, vx, vy, vv; };
+inline double seg_point_dist(const Seg &e, double x, double y) {
   const double wx = x - e.sx, wy = y - e.sy;
   double t = (e.vv > 0.0) ? (wx * e.vx + wy * e.vy) / e.vv : 0.0;
   t = std::min(1.0, std::max(0.0, t));
@@ -166,7 +194,7 @@ inline double rect_point_dist(double x0, double y0, double x1, double y1, double
   return std::hypot(dx, dy);
 }
 // does the segment meet the closed rectangle?  (Liang-Barsky clip of the parameter range)
-inline bool seg_meets_rect(const PolyEdge &e, double x0, double y0, double x1, double y1) {
+inline bool seg_meets_rect(const Seg &e, double x0, double y0, double x1, double y1) {
   double t0 = 0.0, t1 = 1.0;
   const double p[4] = {-e.vx, e.vx, -e.vy, e.vy};
   const double q[4] = {e.sx - x0, x1 - e.sx, e.sy - y0, y1 - e.sy};
@@ -180,7 +208,7 @@ inline bool seg_meets_rect(const PolyEdge &e, double x0, double y0, double x1, d
 }
 // exact distance between a closed rectangle and a segment (two convex sets: zero when they meet, else attained at a
 // vertex of one of them)
-inline double rect_seg_dist(const PolyEdge &e, double x0, double y0, double x1, double y1) {
+inline double rect_seg_dist(const Seg &e, double x0, double y0, double x1, double y1) {
   if (seg_meets_rect(e, x0, y0, x1, y1)) return 0.0;
   double d = std::min(rect_point_dist(x0, y0, x1, y1, e.sx, e.sy), rect_point_dist(x0, y0, x1, y1, e.ex, e.ey));
   d = std::min(d, seg_point_dist(e, x0, y0));
@@ -189,24 +217,43 @@ inline double rect_seg_dist(const PolyEdge &e, double x0, double y0, double x1, 
   d = std::min(d, seg_point_dist(e, x1, y1));
   return d;
 }
+// a candidate list (ascending edge indices) as a record; long lists go to `over`
+inline PolyRec pack_list(const std::vector<unsigned short> &list, std::vector<unsigned short> &over) {
+  unsigned short w[16] = {0};
+  w[0] = (unsigned short)list.size();
+  if (list.size() <= (size_t)kPolyInline) {
+    for (size_t k = 0; k < list.size(); ++k) w[1 + k] = list[k];
+  } else {
+    const unsigned off = (unsigned)over.size();
+    w[1] = (unsigned short)(off & 0xffffu);
+    w[2] = (unsigned short)(off >> 16);
+    over.insert(over.end(), list.begin(), list.end());
+  }
+  PolyRec r;
+  for (int k = 0; k < 4; ++k)
+    r.q[k] = (unsigned long long)w[4 * k] | ((unsigned long long)w[4 * k + 1] << 16) | ((unsigned long long)w[4 * k + 2] << 32) |
+             ((unsigned long long)w[4 * k + 3] << 48);
+  return r;
+}
 }  // namespace poly_detail
 
-// returns false when the outline cannot be handled (n out of range, non-finite or repeated consecutive vertices)
+// returns false when the outline cannot be handled (n out of range, non-finite vertex)
 inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng_fine = 128, int ng_coarse = 128,
                              int nslab = 256) {
   using namespace poly_detail;
   if (n < 3 || n > kPolyMaxVerts) return false;
   out = PolyAccelHost{};
   out.edges.resize(n);
+  std::vector<Seg> seg(n);
   double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
   for (int i = 0; i < n; ++i) {
     const int j = (i + 1 == n) ? 0 : i + 1;
-    PolyEdge &e = out.edges[i];
+    Seg &e = seg[i];
     e.sx = xy[2 * i]; e.sy = xy[2 * i + 1]; e.ex = xy[2 * j]; e.ey = xy[2 * j + 1];
     if (!std::isfinite(e.sx) || !std::isfinite(e.sy)) return false;
     e.vx = e.ex - e.sx; e.vy = e.ey - e.sy;       // Eigen::Vector2d v = end - start
     e.vv = e.vx * e.vx + e.vy * e.vy;             // v.squaredNorm()
-    e.pad = 0.0;
+    out.edges[i] = PolyEdge{e.sx, e.sy, e.vx, e.vy, e.vv};
     xmin = std::min(xmin, e.sx); xmax = std::max(xmax, e.sx);
     ymin = std::min(ymin, e.sy); ymax = std::max(ymax, e.sy);
   }
@@ -220,6 +267,7 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
   const double grow = 1e-7 * scale;   // every cell is enlarged by this on all sides: a query whose cell index is decided
                                       // by the last bit of (x - x0) * inv_h is still covered by the neighbour's list
   std::vector<double> ub(n), row[2];
+  std::vector<unsigned short> list;
   for (int l = 0; l < 2; ++l) {
     PolyLevel &lv = h.lv[l];
     const double m = margins[l];
@@ -230,7 +278,7 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     lv.y0 = 0.5 * (ymin + ymax) - 0.5 * ext;
     lv.inv_h = 1.0 / hcell;
     lv.nx = ng; lv.ny = ng;
-    lv.base = (unsigned)out.cell_off.size();
+    lv.base = (unsigned)out.cells.size();
     lv.pad = 0;
     // distances grid node -> edge, one node row at a time (a node is a corner of up to four cells)
     auto fill_row = [&](std::vector<double> &r, int iy) {
@@ -238,7 +286,7 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
       const double y = lv.y0 + iy * hcell;
       for (int ix = 0; ix <= ng; ++ix) {
         const double x = lv.x0 + ix * hcell;
-        for (int i = 0; i < n; ++i) r[(size_t)ix * n + i] = seg_point_dist(out.edges[i], x, y);
+        for (int i = 0; i < n; ++i) r[(size_t)ix * n + i] = seg_point_dist(seg[i], x, y);
       }
     };
     fill_row(row[0], 0);
@@ -247,7 +295,6 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
       fill_row(row[(iy + 1) & 1], iy + 1);
       const std::vector<double> &r0 = row[iy & 1], &r1 = row[(iy + 1) & 1];
       for (int ix = 0; ix < ng; ++ix) {
-        out.cell_off.push_back((unsigned)out.cand.size());
         const double cx0 = lv.x0 + ix * hcell - grow, cx1 = lv.x0 + (ix + 1) * hcell + grow;
         const double cy0 = lv.y0 + iy * hcell - grow, cy1 = lv.y0 + (iy + 1) * hcell + grow;
         // U >= the nearest-edge distance of every point of the enlarged cell: the distance to a segment is convex
@@ -257,17 +304,20 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
           const double dmax = std::max(std::max(r0[(size_t)ix * n + i], r0[(size_t)(ix + 1) * n + i]),
                                        std::max(r1[(size_t)ix * n + i], r1[(size_t)(ix + 1) * n + i])) + 1.4143 * grow;
           // (a zero-length edge -- repeated vertex -- never wins the reference's `dis < dis_min`: 0/0 gives NaN)
-          ub[i] = (out.edges[i].vv > 0.0) ? dmax : 1e300;
+          ub[i] = (seg[i].vv > 0.0) ? dmax : 1e300;
           U = std::min(U, ub[i]);
         }
         const double thr = U * (1.0 + 1e-9) + 1e-9 * scale;
+        list.clear();
         for (int i = 0; i < n; ++i) {
           if (ub[i] - diam > thr) continue;   // cheap reject (1-Lipschitz): every point of the cell is farther than thr
-          if (rect_seg_dist(out.edges[i], cx0, cy0, cx1, cy1) <= thr) out.cand.push_back((unsigned short)i);
+          if (rect_seg_dist(seg[i], cx0, cy0, cx1, cy1) <= thr) list.push_back((unsigned short)i);
         }
+        out.cand_total += list.size();
+        out.cand_max = std::max(out.cand_max, list.size());
+        out.cells.push_back(pack_list(list, out.over));
       }
     }
-    out.cell_off.push_back((unsigned)out.cand.size());
   }
   // ---- parity slabs
   h.nslab = std::max(1, nslab);
@@ -276,16 +326,17 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
   const double hs = std::max(ymax - ymin, 1e-300) / h.nslab;
   h.slab_inv_h = 1.0 / hs;
   for (int s = 0; s < h.nslab; ++s) {
-    out.slab_off.push_back((unsigned)out.slab_edges.size());
     // queries mapped to slab s have y in [ymin + s hs, ymin + (s + 1) hs] up to rounding of the index (the first and
     // last slab also take the queries within tol outside the y-range); listed: edges within 2 tol of that interval
     const double a = ymin + s * hs - ((s == 0) ? 3.0 : 2.0) * h.tol, b = ymin + (s + 1) * hs + ((s + 1 == h.nslab) ? 3.0 : 2.0) * h.tol;
+    list.clear();
     for (int i = 0; i < n; ++i) {
-      const PolyEdge &e = out.edges[i];
-      if (std::max(e.sy, e.ey) >= a && std::min(e.sy, e.ey) <= b) out.slab_edges.push_back((unsigned short)i);
+      const Seg &e = seg[i];
+      if (std::max(e.sy, e.ey) >= a && std::min(e.sy, e.ey) <= b) list.push_back((unsigned short)i);
     }
+    out.slab_max = std::max(out.slab_max, list.size());
+    out.slabs.push_back(pack_list(list, out.over));
   }
-  out.slab_off.push_back((unsigned)out.slab_edges.size());
   return true;
 }
 }  // namespace svsdf

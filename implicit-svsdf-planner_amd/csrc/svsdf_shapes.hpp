@@ -30,7 +30,9 @@ struct ShapeParams {
   double r_bound;             // conservative circumradius about the body-frame origin (culling)
   int identity;               // trans == 0 and Rotate == I (poly_params = 0): the transform is exact identity
   int nverts;                 // Polygon: outline vertices
-  const PolyAccel *accel;     // Polygon: device pointer to the outline's edges + candidate lists (svsdf_polygon.hpp)
+  const PolyAccel *accel;     // Polygon: device pointer to the outline's candidate lists (svsdf_polygon.hpp)
+  const PolyEdge *edges;      // Polygon: the outline's edges (global memory; k_solve / k_round point it at their LDS copy)
+  int edges_lds;              // Polygon: 1 = the solve / round kernels stage the edges into LDS (host decision)
 };
 
 // std::max / std::min.  Strict builds keep the compare+select form; the default uses v_max_f64 /
@@ -265,7 +267,7 @@ __device__ __forceinline__ double shape_core(const ShapeParams &sp, double px, d
 template <int SHAPE>
 __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, double y) {
   if constexpr (SHAPE == kPolygon) {
-    return poly_sdf<false>(*sp.accel, x, y, nullptr, nullptr);
+    return poly_sdf<false>(*sp.accel, sp.edges, x, y, nullptr, nullptr);
   } else {
     double px = x, py = y;
     if (!sp.identity) {  // wave-uniform; with trans = 0, Rotate = I the products below are exact no-ops
@@ -297,7 +299,7 @@ __device__ __forceinline__ void shape_grad(const ShapeParams &sp, double x, doub
                                            double &gy) {
   if constexpr (SHAPE == kPolygon) {
     double cx, cy;
-    const double sd = poly_sdf<true>(*sp.accel, x, y, &cx, &cy);
+    const double sd = poly_sdf<true>(*sp.accel, sp.edges, x, y, &cx, &cy);
     double vx = x - cx, vy = y - cy;
     const double z = vx * vx + vy * vy;
     if (z > 0.0) { const double n = sqrt(z); vx = vx / n; vy = vy / n; }

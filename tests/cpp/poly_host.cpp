@@ -10,34 +10,29 @@ using namespace svsdf;
 
 extern "C" {
 
-// stats_out[0..5]: fine-grid cells, coarse-grid cells, candidates (all cells), largest candidate list, slab entries,
-// largest slab list
+// stats_out[0..5]: fine-grid cells, coarse-grid cells, candidates (all cells), largest candidate list, entries in
+// long lists, largest slab list
 int polyhost_eval(const double *xy, int n, const double *pts, size_t P, double *sdf_out, double *sdfc_out,
                   double *closest_out, long long *stats_out) {
   PolyAccelHost h;
   if (!build_poly_accel(xy, n, h)) return 1;
   PolyAccel pa = h.hdr;
   pa.edges = h.edges.data();
-  pa.cell_off = h.cell_off.data();
-  pa.cand = h.cand.data();
-  pa.slab_off = h.slab_off.data();
-  pa.slab_edges = h.slab_edges.data();
+  pa.cells = h.cells.data();
+  pa.slabs = h.slabs.data();
+  pa.over = h.over.data();
   for (size_t i = 0; i < P; ++i) {
     const double x = pts[2 * i], y = pts[2 * i + 1];
-    if (sdf_out) sdf_out[i] = poly_sdf<false>(pa, x, y, nullptr, nullptr);
-    if (sdfc_out) sdfc_out[i] = poly_sdf<true>(pa, x, y, closest_out + 2 * i, closest_out + 2 * i + 1);
+    if (sdf_out) sdf_out[i] = poly_sdf<false>(pa, pa.edges, x, y, nullptr, nullptr);
+    if (sdfc_out) sdfc_out[i] = poly_sdf<true>(pa, pa.edges, x, y, closest_out + 2 * i, closest_out + 2 * i + 1);
   }
   if (stats_out) {
     stats_out[0] = (long long)pa.lv[0].nx * pa.lv[0].ny;
     stats_out[1] = (long long)pa.lv[1].nx * pa.lv[1].ny;
-    stats_out[2] = (long long)h.cand.size();
-    long long mx = 0;
-    for (size_t c = 0; c + 1 < h.cell_off.size(); ++c) mx = std::max<long long>(mx, (long long)h.cell_off[c + 1] - (long long)h.cell_off[c]);
-    stats_out[3] = mx;
-    stats_out[4] = (long long)h.slab_edges.size();
-    long long ms = 0;
-    for (int s = 0; s < pa.nslab; ++s) ms = std::max<long long>(ms, (long long)h.slab_off[s + 1] - (long long)h.slab_off[s]);
-    stats_out[5] = ms;
+    stats_out[2] = (long long)h.cand_total;
+    stats_out[3] = (long long)h.cand_max;
+    stats_out[4] = (long long)h.over.size();
+    stats_out[5] = (long long)h.slab_max;
   }
   return 0;
 }
@@ -50,9 +45,8 @@ int polyhost_visits(const double *xy, int n, const double *pts, size_t P, int *l
     int cell = poly_cell(h.hdr.lv[0], pts[2 * i], pts[2 * i + 1]), lvl = 0;
     if (cell < 0) { cell = poly_cell(h.hdr.lv[1], pts[2 * i], pts[2 * i + 1]); lvl = 1; }
     if (cell < 0) { level_out[i] = 2; count_out[i] = n; continue; }
-    const unsigned b = h.hdr.lv[lvl].base;
     level_out[i] = lvl;
-    count_out[i] = (int)(h.cell_off[b + cell + 1] - h.cell_off[b + cell]);
+    count_out[i] = (int)(h.cells[h.hdr.lv[lvl].base + cell].q[0] & 0xffffull);
   }
   return 0;
 }
