@@ -14,9 +14,12 @@ Workloads (svsdf_amd/workload.py, BASELINE.json `configs`):
                       full-callback time (a14: MINCO forward + penalty + adjoint).
   --gpus N > 1        C4 = configs[3]: sdHeart, 32 pieces, 4 M points in total, striped over the N GPUs
                       (strong scaling), one sum of the (19N+1)-double partial per evaluation:
-                        torchrun, one process per GPU  -> RCCL all-reduce (torch.distributed), or
-                        --inprocess, ONE process        -> the C ABI's multi-device context (host combine or
-                                                           in-process RCCL, --combine).
+                        launched by torchrun (WORLD_SIZE set), one process per GPU -> RCCL all-reduce
+                                                           (torch.distributed), or
+                        plain `python bench.py --gpus N` -> ONE process drives devices 0..N-1 through the C ABI's
+                                                           multi-device context (host combine or in-process RCCL,
+                                                           --combine); refuses to run when fewer than N GPUs are
+                                                           visible unless --devices repeats ordinals on purpose.
   --config / --points / --dist override the workload (C1..C5, NS).
 
     python bench.py --gpus N --steps K --warmup W
@@ -35,9 +38,10 @@ for p in (ROOT, os.path.join(ROOT, "implicit-svsdf-planner_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# The library runs large shards as 4 point batches on their own HIP streams; streams that share one of the runtime's
-# hardware queues (default 4) serialise.  Must be set before the HIP runtime initialises, i.e. before `import torch`
-# (the C++ host of INTEGRATION.md gets the same setting from svsdf_create itself).
+# The library can run a large shard as up to 4 point batches on their own HIP streams; streams that share one of the
+# runtime's hardware queues (default 4) serialise.  This is the HOST's setting: it must be in the
+# environment before the HIP runtime initialises, i.e. before `import torch`.  The library itself never touches it -- it
+# times 1 / 3 / 4 batches on the first evaluations after svsdf_set_points and keeps the fastest (svsdf_stats.batches).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
@@ -45,7 +49,10 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector peak = 1/2 of the 157.3 TF FP32 vector figure
 BYTES_PER_POINT = 24.0     # algorithmic bytes per query point per evaluation (3 x f64)
-FLOP_PER_EVAL = 150.0      # nominal FP64 flop per SDF-at-time evaluation
+FP64_NOFMA_TFLOPS = 39.3   # the same VALU rate without FMA (the parity build is -ffp-contract=off: one flop per lane-op)
+FLOP_PER_EVAL = 150.0      # nominal FP64 flop per full SDF-at-time evaluation: polynomial 36 + sincos ~60 + transform 10 +
+                           # shape ~45
+FLOP_PER_TABLE_EVAL = 55.0 # a layer-1 TABLE evaluation (pose from the LDS table): transform 10 + shape ~45 only
 
 
 def parse():
@@ -57,7 +64,8 @@ def parse():
     ap.add_argument("--points", type=int, default=None, help="TOTAL query points (default: the config's)")
     ap.add_argument("--dist", default="corridor", choices=["corridor", "map"])
     ap.add_argument("--inprocess", action="store_true",
-                    help="one process drives --gpus devices through the C ABI's multi-device context")
+                    help="one process drives --gpus devices through the C ABI's multi-device context (the default "
+                         "for --gpus N > 1 when not launched by torchrun)")
     ap.add_argument("--devices", default=None, help="comma list of HIP ordinals for --inprocess (default 0..N-1; "
                     "an ordinal may repeat to emulate several stripes on one GPU)")
     ap.add_argument("--combine", default="auto", choices=["auto", "host", "rccl"])
@@ -133,24 +141,31 @@ class Runner:
         torch.cuda.synchronize()
 
     def settle(self):
-        """Setup after set_points, outside every timed region: the first evaluation decides the GSIP bound
-        mode (deterministic rule, svsdf_stats.bound_ratio), the second records the launch plan of that mode."""
+        """Setup after set_points, outside every timed region: the first evaluations decide the GSIP bound mode
+        (deterministic rule, svsdf_stats.bound_ratio), learn the launch widths and -- for a large shard in a scanning
+        mode -- time 1 / 3 / 4 point batches once each (svsdf_stats.plan_settled; all of them return identical results)."""
         t0 = time.perf_counter()
         self.step()
         first_ms = 1e3 * (time.perf_counter() - t0)
-        self.step()
+        n = 1
+        while n < 8:
+            self.step()
+            n += 1
+            if self.ctx.stats()["plan_settled"]:
+                break
         st = self.ctx.stats()
         return {"set_points_ms": self.set_points_ms, "set_points_library_ms": st["setup_ms"],
-                "first_evaluation_ms": first_ms, "settle_evaluations": 2,
+                "first_evaluation_ms": first_ms, "settle_evaluations": n, "batches": st["batches"],
                 "gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][st["gsip_bound_mode"]],
                 "bound_ratio": st["bound_ratio"], "rule": "deterministic, from the first evaluation's counters: GSIP solves / "
-                "samples > 0.5 -> full-scan; else lazy-scan from 400 k points per device, cheap-chunk below"}
+                "samples > 0.5 (Polygon 0.2) -> full-scan; else lazy-scan from 400 k points per device, cheap-chunk below; "
+                "batches: 1 / 3 / 4 timed once each on a large shard in a scanning mode, fastest kept"}
 
     def timed(self, steps, warmup):
         for _ in range(warmup):
             self.step()
         self.fence()
-        acc = dict(sdf_evals=0, scan_evals=0, solves=0, solve_launches=0, gsip_samples=0)
+        acc = dict(sdf_evals=0, scan_evals=0, solves=0, solve_launches=0, gsip_samples=0, round_scan_evals=0)
         last = None
         combine_ms = 0.0
         t0 = time.perf_counter()
@@ -165,28 +180,61 @@ class Runner:
         return elapsed, acc, last, combine_ms / steps
 
     def profiled(self, steps):
-        """Kernel time of the dominant kernel: separate passes with per-launch HIP events on the library's own
+        """Kernel times of k_solve and k_round: separate passes with per-launch HIP events on the library's own
         streams (an event record costs ~6 us per launch, so it stays out of the timed region)."""
         self.ctx.set_profiling(True)
-        solve_ms = dev_ms = self.solve_ms_sum = 0.0
+        solve_ms = dev_ms = self.solve_ms_sum = self.round_ms = self.round_ms_sum = 0.0
         for _ in range(steps):
             self.step()
             st = self.ctx.stats()
             solve_ms += st["solve_ms"]
             dev_ms += st["device_ms"]
             self.solve_ms_sum += st["solve_ms_sum"] / steps
+            self.round_ms += st["round_ms"] / steps
+            self.round_ms_sum += st["round_ms_sum"] / steps
         # the same with the point batches run one after the other: a launch's duration is then its own cost
         self.ctx.set_profiling(2)
-        self.solve_ms_serial = self.dev_ms_serial = 0.0
+        self.solve_ms_serial = self.dev_ms_serial = self.round_ms_serial = 0.0
         self.step()
         for _ in range(steps):
             self.step()
             st = self.ctx.stats()
             self.solve_ms_serial += st["solve_ms"] / steps
+            self.round_ms_serial += st["round_ms"] / steps
             self.dev_ms_serial += st["device_ms"] / steps
         self.ctx.set_profiling(False)
         self.step()
         return solve_ms / steps, dev_ms / steps
+
+    def generic_durations(self, steps, seed=11):
+        """The regime an optimisation is in after its first callback: piece durations are generic doubles (here every
+        tau gets a fixed relative perturbation of 1e-3 N(0,1), the waypoints stay), so the reference's chain of
+        subtractions for the piece-local time runs (svsdf_stats.piece_time_exact = 1).  Timed exactly like the headline:
+        `steps` evaluations of the inner operator on ONE fixed perturbed trajectory, fenced on both sides."""
+        import svsdf_amd
+        rng = np.random.default_rng(seed)
+        N = self.N
+        x = self.x.copy()
+        x[:N] *= 1.0 + 1e-3 * rng.standard_normal(N)
+        T = svsdf_amd.forward_T(x[:N])
+        coeffs = svsdf_amd.minco_coeffs(self.w["head_state"], self.w["tail_state"], x[N:].reshape(-1, 3), T)
+        f = lambda: self.opt.addSaftyPenaOnSweptVolumeParallelTrueSDF(T, coeffs, 0.0, self.zT, self.zC)
+        for _ in range(3):
+            f()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f()
+        self.fence()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        st = self.ctx.stats()
+        for _ in range(2):
+            self.step()     # back on the headline trajectory (launch plan)
+        return {"ms_per_step": ms, "value": self.P_total / (ms * 1e-3), "unit": "query-points/s", "steps": steps,
+                "piece_time_exact": st["piece_time_exact"],
+                "note": "same workload, piece durations 2.5 s * (1 + ~1e-3 N(0,1)) (generic doubles): the reference-faithful "
+                        "chain of subtractions for the piece-local time runs; this is what every LMBM iterate after the "
+                        "first one sees"}
 
     def full_callback(self, steps, perturb=0.0, seed=7):
         """a14: costFunctionLmbmParallel (tau -> T, MINCO forward, penalty, adjoint, chain rule).  With
@@ -217,19 +265,51 @@ def allreduce_ms(tdist, n, reps=50):
     return 1e3 * (time.perf_counter() - t0) / reps
 
 
+def fp64_accounting(acc, steps, solve_ms, solve_ms_serial, round_ms, round_ms_serial, ms_per_step, ndev=1):
+    """FP64 figures per kernel from the kernels' own counters (svsdf_stats): k_solve = its full evaluations x 150 flop +
+    its table evaluations x 55 flop over ITS time; k_round = its table evaluations x 55 flop over ITS time; the whole
+    evaluation = all of it over the driver-visible ms_per_step.  Fractions of the 78.6 TFLOP/s vector peak (FMA = 2 flop)
+    and, beside it, of the 39.3 TFLOP/s the no-FMA parity build can reach at best."""
+    e_tab = acc["scan_evals"] / steps / ndev
+    e_full = (acc["sdf_evals"] - acc["scan_evals"]) / steps / ndev
+    e_round = acc["round_scan_evals"] / steps / ndev
+    fl_solve = e_full * FLOP_PER_EVAL + e_tab * FLOP_PER_TABLE_EVAL
+    fl_round = e_round * FLOP_PER_TABLE_EVAL
+    tf = lambda fl, ms: fl / max(ms, 1e-9) / 1e9          # flop / ms -> TFLOP/s
+    def obj(fl, ms):
+        return {"achieved": tf(fl, ms), "frac": tf(fl, ms) / FP64_PEAK_TFLOPS, "frac_of_no_fma_ceiling": tf(fl, ms) / FP64_NOFMA_TFLOPS,
+                "ms": ms, "gflop": fl / 1e9}
+    return {"bound": "fp64_valu", "peak": FP64_PEAK_TFLOPS, "peak_no_fma": FP64_NOFMA_TFLOPS, "unit": "TFLOP/s",
+            "flop_per_full_eval_nominal": FLOP_PER_EVAL, "flop_per_table_eval_nominal": FLOP_PER_TABLE_EVAL,
+            "k_solve_full_evals_per_step": e_full, "k_solve_table_evals_per_step": e_tab, "k_round_table_evals_per_step": e_round,
+            "k_solve": obj(fl_solve, solve_ms), "k_solve_serialized": obj(fl_solve, solve_ms_serial),
+            "k_round": obj(fl_round, round_ms), "k_round_serialized": obj(fl_round, round_ms_serial),
+            "whole_evaluation": obj(fl_solve + fl_round, ms_per_step),
+            # headline fraction of this object: k_solve's own work over k_solve's own (merged) time
+            "achieved": tf(fl_solve, solve_ms), "frac": tf(fl_solve, solve_ms) / FP64_PEAK_TFLOPS,
+            "note": "per kernel: evaluations counted by that kernel / that kernel's HIP-event time (merged intervals of its "
+                    "concurrent launches; *_serialized: batches run one after the other); table evaluations skip the "
+                    "polynomial and sincos (55 of the nominal 150 flop); no FMA by policy, so 39.3 TFLOP/s is the ceiling"}
+
+
 def sub_run(a, name, P, dist_name, rank, world, local_rank, tdist, devices, steps):
     r = Runner(a, name, P, dist_name, rank, world, local_rank, tdist, devices)
     setup = r.settle()
     elapsed, acc, last, _ = r.timed(steps, 2)
     solve_ms, dev_ms = r.profiled(min(steps, 3))
+    ms_step = 1e3 * elapsed / steps
+    fp = fp64_accounting(acc, steps, solve_ms, r.solve_ms_serial, r.round_ms, r.round_ms_serial, ms_step)
     out = {"workload": f"{name}: {r.w['shape']}, {r.N} pieces, {P} {dist_name} points", "points_total": P,
-           "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "value": P * steps / elapsed,
+           "steps": steps, "ms_per_step": ms_step, "value": P * steps / elapsed,
            "unit": "query-points/s", "interior_fraction": last["interior_points"] / max(last["points"], 1),
            "culled_fraction": last["culled_points"] / max(last["points"], 1),
            "argmin_solves_per_point": acc["solves"] / steps / max(last["points"], 1),
-           "gsip_bound_mode": setup["gsip_bound_mode"], "k_solve_ms_per_step": solve_ms,
-           "fp64_frac": (acc["sdf_evals"] / steps) * FLOP_PER_EVAL / (solve_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+           "gsip_bound_mode": setup["gsip_bound_mode"], "batches": setup["batches"], "k_solve_ms_per_step": solve_ms,
+           "k_round_ms_per_step": r.round_ms,
+           "fp64_frac_k_solve": fp["k_solve"]["frac"], "fp64_frac_k_round": fp["k_round"]["frac"],
+           "fp64_frac_whole_evaluation": fp["whole_evaluation"]["frac"],
            "hbm_frac": BYTES_PER_POINT * last["points"] / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "generic_durations": r.generic_durations(steps),
            "full_callback_ms": r.full_callback(min(steps, 5))}
     r.opt._ctx.close()
     return out
@@ -261,13 +341,20 @@ def main():
             tdist.init_process_group(backend, rank=rank, world_size=world)
     devices = None
     n_gpus = world
+    if world == 1 and a.gpus > 1:
+        a.inprocess = True      # plain `python bench.py --gpus N`: ONE process drives N devices through the C ABI
     if a.inprocess:
         if world != 1:
             raise SystemExit("--inprocess is a single-process mode (do not launch it with torchrun)")
         devices = [int(v) for v in a.devices.split(",")] if a.devices else list(range(a.gpus))
+        if not a.devices and torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible; pass --devices "
+                             "with repeated ordinals to put several stripes on one GPU on purpose")
         n_gpus = len(devices)
         if n_gpus < 2 and a.combine != "rccl":   # (one device + rccl: a 1-rank communicator, measures the collective's fixed cost)
             devices = None
+    elif world > 1 and a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     multi = n_gpus > 1
     name = a.config or ("C4" if multi else "C3")
     P_total = a.points or workload.CONFIGS[name]["P"]
@@ -282,6 +369,7 @@ def main():
     cb_steps = max(1, min(a.steps, 10))
     full_cb_ms = r.full_callback(cb_steps)
     full_cb_pert_ms = r.full_callback(cb_steps, perturb=1e-3)
+    generic = r.generic_durations(max(1, min(a.steps, 20))) if not (tdist is not None or (a.inprocess and a.gpus > 1)) else None
     shard_points = last["points"]          # points resident on this process' device(s)
     evals_rank, interior_rank = acc["sdf_evals"], last["interior_points"]
     ar_ms = None
@@ -315,7 +403,8 @@ def main():
     # dominant kernel = k_solve: rank-0 (in-process: slowest device) HIP-event time on the library's own streams
     pts_dev = shard_points / (n_gpus if a.inprocess and multi else 1)
     ach_gbs = BYTES_PER_POINT * pts_dev / (solve_ms_step * 1e-3) / 1e9
-    ach_tf = (evals_rank / a.steps / (n_gpus if a.inprocess and multi else 1)) * FLOP_PER_EVAL / (solve_ms_step * 1e-3) / 1e12
+    fp64 = fp64_accounting(acc, a.steps, solve_ms_step, r.solve_ms_serial, r.round_ms, r.round_ms_serial, ms_per_step,
+                           ndev=(n_gpus if a.inprocess and multi else 1))
     traffic = None
     try:  # PMC-derived HBM traffic of k_solve per evaluation (collected offline, see profiles/)
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -354,7 +443,7 @@ def main():
                      "traffic": traffic,
                      "traffic_unit": "bytes per evaluation (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                      "kernel_ms_per_step": solve_ms_step, "kernel_ms_sum_per_step": r.solve_ms_sum,
-                     "kernel_time_note": "the shard runs as 4 point batches on concurrent streams: kernel_ms_per_step = time "
+                     "kernel_time_note": "a large shard runs as several point batches on concurrent streams (setup.batches): kernel_ms_per_step = time "
                                          "during which at least one k_solve launch was executing (merged HIP-event intervals; "
                                          "what `achieved` divides by), kernel_ms_sum_per_step = plain sum of the launch durations "
                                          "(what a rocprofv3 kernel trace adds up: launches x average duration)",
@@ -365,12 +454,12 @@ def main():
                      "launches_per_step": acc["solve_launches"] / a.steps,
                      "device_ms_per_step": dev_ms_step, "profiled_steps": prof_steps,
                      "note": "24 B/point algorithmic; the solve is FP64-VALU bound (SURVEY.md §8d), see fp64",
-                     "fp64": {"bound": "fp64_valu", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach_tf / FP64_PEAK_TFLOPS,
-                              "frac_serialized": ach_tf * solve_ms_step / max(r.solve_ms_serial, 1e-9) / FP64_PEAK_TFLOPS,
-                              "sdf_evals_per_step": evals_all / a.steps, "layer1_evals_per_step": scan_all / a.steps,
-                              "flop_per_eval_nominal": FLOP_PER_EVAL}},
+                     "k_round_ms_per_step": r.round_ms, "k_round_ms_sum_per_step": r.round_ms_sum,
+                     "k_round_ms_serialized_per_step": r.round_ms_serial,
+                     "fp64": fp64},
     }
+    if generic is not None:
+        res["generic_durations"] = generic
     if multi or devices is not None or ar_ms is not None:
         res["combine"] = {"ms_allreduce": ar_ms, "ms_combine_inprocess": combine_ms if a.inprocess else None,
                           "mode": ["host", "host", "rccl"][last["combine"]] if a.inprocess else "torch.distributed",

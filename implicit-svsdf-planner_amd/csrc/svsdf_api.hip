@@ -90,6 +90,7 @@ struct svsdf_ctx {
   hipStream_t bstream[kMaxBatches] = {};      // one stream per point batch
   hipEvent_t ev_prep = nullptr, ev_done[kMaxBatches] = {};
   ShapeParams sp{};
+  bool poly_lds = false;             // Polygon: k_solve / k_round run their kPolygonLds variants (edges at the start of LDS)
   unsigned char *d_poly = nullptr;   // Polygon: one device blob [PolyAccel | edges | cell records | slab records | long lists]
   std::vector<double> poly_xy;       // Polygon: the outline as given (host copy)
   std::string err;
@@ -124,13 +125,7 @@ struct svsdf_ctx {
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
   bool block_env = false;      // env SVSDF_BLOCK pins the solve kernel's block size (default: by LDS footprint)
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
-  bool persistent = false;   // SVSDF_PERSISTENT=1: one k_gsip launch per batch instead of the k_solve / k_round chain
-  int gsip_blocks_per_cu = 0;   // resident blocks of k_gsip per CU (occupancy query, cached per block size / LDS / mode)
-  long long gsip_key[3] = {0, 0, -1};
   int n_cu = 256;
-  int gsip_grace = 32;      // polls a wave waits for the rest of a reserved ticket once its first entry is there
-  int gsip_from = 0;         // SVSDF_PERSISTENT_FROM: GSIP iterations that still run as launches before k_gsip takes over
-  int gsip_error = 0;        // k_gsip gave up (queue overflow / poll cap): the evaluation is rerun through the chain
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
   bool ub_lazy = false;        // with ub_full: only the samples in the cheap-bound band are scanned (k_round MODE 2)
@@ -142,6 +137,10 @@ struct svsdf_ctx {
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
   int G_env = 0, G_late_env = 0;
+  // batch count of a large shard in the scanning bound modes: chosen by timing real evaluations (any split gives the
+  // same bits): 0 idle / done, 1 next evaluation learns the launch plan with one batch, 2.. timing candidate bt_k
+  int bt_state = 0, bt_k = 0, bt_ncand = 0, bt_cand[3] = {1, 1, 1};
+  double bt_ms[3] = {0, 0, 0};
   long long prev_nsolve[kMaxIter] = {};  // solves per GSIP iteration of the previous evaluation (same point set)
   bool have_prev_nsolve = false;
   long long wide32_below = 2000, wide16_below = 5000, wide8_below = 40000;  // env SVSDF_WIDE32 / SVSDF_WIDE16 / SVSDF_WIDE8
@@ -173,7 +172,8 @@ struct svsdf_ctx {
   int saved_nbatch = 0;  // svsdf_set_profiling(ctx, 2): the batch split to restore
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  std::vector<std::pair<size_t, size_t>> refine_events;  // (start, stop) indices into ev_pool
+  std::vector<std::pair<size_t, size_t>> refine_events;  // k_solve launches: (start, stop) indices into ev_pool
+  std::vector<std::pair<size_t, size_t>> round_events;   // k_round launches
   svsdf_stats stats{};
 
   // in-process multi-GPU group (svsdf_config::n_devices > 1): this context then owns no device state of its
@@ -198,7 +198,7 @@ struct svsdf_ctx {
 namespace {
 
 constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 10 + kMaxIter;   // partial | 9 counters | solves per iteration | k_gsip error
+constexpr size_t kOutDoubles = kOutPartial + 10 + kMaxIter;   // partial | 9 counters | solves per iteration
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -256,7 +256,7 @@ size_t next_event(svsdf_ctx *ctx) {
   }
 int compiled_shape(int shape) {
 #ifdef SVSDF_FAST_BUILD
-  return (shape == 4 || shape == 6 || shape == 7) ? shape : 16;
+  return (shape == 4 || shape == 6 || shape == 7 || shape == kPolygonLds) ? shape : 16;
 #else
   return shape;
 #endif
@@ -274,10 +274,6 @@ bool launch_k_round(int shape, int lp, int mode, unsigned grid, size_t lds, hipS
 bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a) {
   shape = compiled_shape(shape);
   SVSDF_SLICE_DISPATCH(launch_k_classify, grid, lds, st, a)
-}
-bool launch_k_gsip(int shape, int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a) {
-  shape = compiled_shape(shape);
-  SVSDF_SLICE_DISPATCH(launch_k_gsip, mode, grid, block, lds, st, a)
 }
 bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out) {
   shape = compiled_shape(shape);
@@ -307,7 +303,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
                   double cull_thresh = std::numeric_limits<double>::infinity()) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
-  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + poly_lds_doubles(ctx->sp.nverts, ctx->sp.edges_lds)) * sizeof(double);
+  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (ctx->poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
   // Every block stages the pose table + chunk bounds + trajectory into LDS (13 KB at 16 pieces x 2.5 s, 24 KB at 32):
   // with one wave per block that caps the CU at 160 KB / lds waves -- 6 at C3, half of what the kernel's 141 VGPRs
   // allow (3 waves per SIMD) -- so the block grows until LDS no longer binds (measured at C3: 10.7 -> 9.2 ms).
@@ -317,7 +313,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh};
-  (void)launch_k_solve(ctx->cfg.shape_id, G, grid, (unsigned)blk, lds, st, a);
+  (void)launch_k_solve(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds, st, a);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -330,7 +326,7 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;   // k_round MODE: cheap / full / lazy bound
   const bool scans = mode != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
-  const size_t lds = (table_lds_doubles(ctx) + poly_lds_doubles(ctx->sp.nverts, ctx->sp.edges_lds)) * sizeof(double);
+  const size_t lds = (table_lds_doubles(ctx) + (ctx->poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
   // late iterations hold few points and are latency-bound: request every sample there, which
   // avoids supplementary iterations at no cost in time
   // the seed bound of the scanning modes is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
@@ -345,41 +341,14 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, 1024);
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta,
                       band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
-  (void)launch_k_round(ctx->cfg.shape_id, lp, mode, grid, lds, st, a);
-}
-
-// The GSIP loop of batch b from iteration it0 on in one persistent launch (k_gsip), after k_round(it0).
-void launch_gsip(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
-  const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
-  const bool scans = mode != 0;
-  const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
-  const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
-  const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
-  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N)) * sizeof(double);
-  int blk = ctx->block;
-  if (!ctx->block_env) blk = (lds * 12 <= 160 * 1024) ? 64 : (lds * 6 <= 160 * 1024) ? 128 : 256;
-  const long long lanes = std::max<long long>((long long)ctx->bcount[b] * 8, 64);   // ~ 2 solves of 4 lanes per point
-  const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
-  // this batch's shards and rings (twice the batch's worst-case outstanding tasks + the shards' slack)
-  GsipState gsb = ctx->gs;
-  gsb.qsh = ctx->gs.qsh + (size_t)b * kMaxShards;
-  gsb.q = ctx->gs.q + 2 * (size_t)ctx->bstart[b] * kMaxSlots + (size_t)b * kMaxShards * kShardSlack;
-  hipLaunchKernelGGL(k_gsip_init, dim3(1), dim3(kMaxShards), 0, st, ctx->d_ctl + b, gsb.qsh);
-  if (ctx->gsip_key[0] != blk || ctx->gsip_key[1] != (long long)lds || ctx->gsip_key[2] != mode) {
-    ctx->gsip_key[0] = blk; ctx->gsip_key[1] = (long long)lds; ctx->gsip_key[2] = mode;
-    ctx->gsip_blocks_per_cu = 0;
-  }
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  const GsipLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, gsb, ctx->P, sel,
-                     ctx->select_delta, all_it, ctx->gsip_grace, it0, std::max(1, ctx->n_cu / ctx->nbatch), &ctx->gsip_blocks_per_cu, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b};
-  (void)launch_k_gsip(ctx->cfg.shape_id, mode, grid, (unsigned)blk, lds, st, a);
+  (void)launch_k_round(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, lp, mode, grid, lds, st, a);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
-    ctx->refine_events.emplace_back(e0, e1);
+    ctx->round_events.emplace_back(e0, e1);
   }
-  ctx->stats.solve_launches++;
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
@@ -557,6 +526,7 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
   HIPCHK(hipSetDevice(ctx->device));
   ctx->ev_used = 0;
   ctx->refine_events.clear();
+  ctx->round_events.clear();
   ctx->stats = svsdf_stats{};
   ctx->stats.points = ctx->P;
   const size_t e_begin = next_event(ctx);
@@ -577,16 +547,8 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     launch_classify(ctx, st, b);
     launch_round(ctx, st, b, 0);
   }
-  if (ctx->persistent) {
-    // the first gsip_from iterations as launches (their solve lists fill the chip), the rest in one persistent launch
-    const int it0 = std::max(0, std::min(ctx->gsip_from, (int)kMaxIter - 1));
-    for (int it = 0; it < it0; ++it) enqueue_solve_round(ctx, it);
-    for (int b = 0; b < ctx->nbatch; ++b) launch_gsip(ctx, ctx->bstream[b], b, it0);
-    ctx->it_done = it0 + 1;   // k_finish: n_solve[it0 + 1] stays zero, nothing pending
-  } else {
-    for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
-    ctx->it_done = ctx->first_iters;
-  }
+  for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
+  ctx->it_done = ctx->first_iters;
   return join_batches(ctx);
 }
 
@@ -627,8 +589,6 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   int rc = reduce_and_read(ctx, with_partial);
   if (rc) return rc;
   const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out + kOutPartial);
-  ctx->gsip_error = (int)st[9 + kMaxIter];
-  if (ctx->gsip_error) return SVSDF_OK;   // the caller reruns the evaluation through the launch chain
   while (st[5] > 0 && ctx->it_done < kMaxIter) {  // solves requested by the last k_round are pending
     const int it1 = std::min(ctx->it_done + 3, (int)kMaxIter);
     for (int it = ctx->it_done; it < it1; ++it) enqueue_solve_round(ctx, it);
@@ -645,13 +605,13 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.gsip_samples = st[6];
   ctx->stats.gsip_iterations = (unsigned)st[7];
   ctx->stats.culled_points = st[8];
-  if (!ctx->persistent || ctx->gsip_from > 0) {   // (persistent: only the iterations that ran as launches have counts)
-    for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
-    ctx->have_prev_nsolve = true;
-  }
+  ctx->stats.round_scan_evals = st[9 + kMaxIter];
+  ctx->stats.batches = ctx->nbatch;
+  for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
+  ctx->have_prev_nsolve = true;
   // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
   // covers an underestimate
-  if (ctx->adaptive_iters && !ctx->persistent) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
+  if (ctx->adaptive_iters) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
   if (ctx->profile) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
@@ -660,26 +620,28 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
     // [start, stop] intervals (device clock, relative to the evaluation's first event) are merged -- solve_ms is the
     // time during which at least one k_solve launch was executing, solve_ms_sum the plain sum of the launch durations
     // (what a kernel trace adds up)
-    double sum = 0.0;
-    std::vector<std::pair<float, float>> iv;
-    for (const auto &pr : ctx->refine_events) {
-      float a = 0.f, b = 0.f;
-      if (hipEventElapsedTime(&a, ctx->ev_pool[0], ctx->ev_pool[pr.first]) == hipSuccess &&
-          hipEventElapsedTime(&b, ctx->ev_pool[0], ctx->ev_pool[pr.second]) == hipSuccess && b >= a) {
-        iv.emplace_back(a, b);
-        sum += b - a;
+    auto merged = [&](const std::vector<std::pair<size_t, size_t>> &evs, double &uni, double &sum) {
+      sum = 0.0;
+      std::vector<std::pair<float, float>> iv;
+      for (const auto &pr : evs) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, ctx->ev_pool[0], ctx->ev_pool[pr.first]) == hipSuccess &&
+            hipEventElapsedTime(&b, ctx->ev_pool[0], ctx->ev_pool[pr.second]) == hipSuccess && b >= a) {
+          iv.emplace_back(a, b);
+          sum += b - a;
+        }
       }
-    }
-    std::sort(iv.begin(), iv.end());
-    double uni = 0.0;
-    float cur_a = 0.f, cur_b = -1.f;
-    for (const auto &x : iv) {
-      if (x.first > cur_b) { if (cur_b >= cur_a) uni += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
-      else cur_b = std::max(cur_b, x.second);
-    }
-    if (cur_b >= cur_a) uni += cur_b - cur_a;
-    ctx->stats.solve_ms = uni;
-    ctx->stats.solve_ms_sum = sum;
+      std::sort(iv.begin(), iv.end());
+      uni = 0.0;
+      float cur_a = 0.f, cur_b = -1.f;
+      for (const auto &x : iv) {
+        if (x.first > cur_b) { if (cur_b >= cur_a) uni += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
+        else cur_b = std::max(cur_b, x.second);
+      }
+      if (cur_b >= cur_a) uni += cur_b - cur_a;
+    };
+    merged(ctx->refine_events, ctx->stats.solve_ms, ctx->stats.solve_ms_sum);
+    merged(ctx->round_events, ctx->stats.round_ms, ctx->stats.round_ms_sum);
   }
   if (st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
@@ -687,27 +649,18 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
 
 int set_batches(svsdf_ctx *ctx, int nb);   // below
 
-// One evaluation up to the per-point results (and the partial): enqueue, finish; when the persistent GSIP kernel gave
-// up (it never should: the queues hold the worst case) the evaluation is repeated through the launch chain and the
-// context stays on the chain.
+// One evaluation up to the per-point results (and the partial): enqueue, finish.
 int evaluate_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bool allow_cull, bool with_partial) {
   int rc = enqueue_queries(ctx, N, coeffs, T, allow_cull);
   if (rc) return rc;
-  rc = finish(ctx, with_partial);
-  if (rc == SVSDF_OK && ctx->gsip_error) {
-    std::fprintf(stderr, "[svsdf] persistent GSIP kernel gave up (code %d); falling back to the launch chain\n", ctx->gsip_error);
-    ctx->persistent = false;
-    ctx->gsip_error = 0;
-    if ((rc = enqueue_queries(ctx, N, coeffs, T, allow_cull))) return rc;
-    rc = finish(ctx, with_partial);
-  }
-  return rc;
+  return finish(ctx, with_partial);
 }
 
 void fill_mode_stats(svsdf_ctx *ctx) {
   ctx->stats.gsip_bound_mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
   ctx->stats.piece_time_exact = ctx->stats_piece_time;
   ctx->stats.bound_mode_decided = (ctx->ub_env || ctx->ub_tune > 0) ? 1 : 0;
+  ctx->stats.plan_settled = (ctx->stats.bound_mode_decided && ctx->bt_state == 0 && ctx->have_prev_nsolve) ? 1 : 0;
   ctx->stats.bound_ratio = ctx->ub_ratio;
   ctx->stats.n_devices = 1;
   ctx->stats.combine = SVSDF_COMBINE_HOST;
@@ -753,13 +706,37 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   // evaluations and without depending on the box.)
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
   if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; }
-  int rc = evaluate_points(ctx, N, coeffs, T, /*allow_cull=*/true, /*with_partial=*/true);
+  // Batch count (large shards in the scanning modes; DESIGN.md "concurrent point batches"): whether 4 batches beat 1
+  // depends on how the HIP runtime maps the batch streams onto hardware queues (GPU_MAX_HW_QUEUES, default 4: streams
+  // that share a queue serialise and the split is then SLOWER than one batch) -- a process-wide setting this library
+  // leaves to the host.  So the count is measured: after the bound mode is known, one evaluation learns the launch
+  // plan, then one evaluation per candidate (1, 4 [2 in the lazy mode], 3) is timed with the wall clock and the
+  // fastest count stays.  Every candidate computes the same bits; the choice only costs time.
+  int rc = SVSDF_OK;
+  const bool timing = ctx->bt_state >= 2;
+  if (timing) rc = set_batches(ctx, ctx->bt_cand[ctx->bt_k]);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (rc == SVSDF_OK) rc = evaluate_points(ctx, N, coeffs, T, /*allow_cull=*/true, /*with_partial=*/true);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (rc == SVSDF_OK && ctx->bt_state == 1) {
+    ctx->bt_state = 2;
+    ctx->bt_k = 0;
+  } else if (rc == SVSDF_OK && timing) {
+    ctx->bt_ms[ctx->bt_k] = ms;
+    if (++ctx->bt_k == ctx->bt_ncand) {
+      int best = 0;
+      for (int k = 1; k < ctx->bt_ncand; ++k)
+        if (ctx->bt_ms[k] < ctx->bt_ms[best]) best = k;
+      rc = set_batches(ctx, ctx->bt_cand[best]);
+      ctx->bt_state = 0;
+    }
+  }
   if (rc == SVSDF_OK && deciding) {
     const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
     const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
     ctx->ub_ratio = ctx->stats.gsip_samples ? (double)gs / (double)ctx->stats.gsip_samples : 0.0;
-    // Polygon: an SDF evaluation costs ~10 x an analytic shape's (one pass over the outline per evaluation), a table
-    // scan proportionally less of a solve, so scanning pays from a lower ratio (C5, 1 M points: 55.5 -> 48.3 ms)
+    // Polygon: an SDF evaluation costs several times an analytic shape's (candidate edges of the outline), a table
+    // scan proportionally less of a solve, so scanning pays from a lower ratio
     const double thr = ctx->ub_thr_env ? ctx->ub_threshold : (ctx->cfg.shape_id == SVSDF_SHAPE_Polygon ? 0.2 : ctx->ub_threshold);
     // below the threshold a large shard still gains from scanning -- but only the samples the cheap bound would have
     // had solved (lazy mode: NS, star / 16 pieces / 1 M points, 12.3 -> 11.4 ms; at 100 k points no gain)
@@ -768,8 +745,13 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
-    // (the persistent GSIP kernel has no per-iteration tails for a second batch to fill: it keeps one batch)
-    if (ctx->ub_full && ctx->want_batches == 0 && large && !(ctx->persistent && ctx->gsip_from == 0)) rc = set_batches(ctx, ctx->ub_lazy ? 2 : 4);
+    if (ctx->ub_full && ctx->want_batches == 0 && large) {
+      ctx->bt_state = 1;
+      ctx->bt_cand[0] = 1;
+      ctx->bt_cand[1] = ctx->ub_lazy ? 2 : 4;
+      ctx->bt_ncand = 2;
+      if (!ctx->ub_lazy) { ctx->bt_cand[2] = 3; ctx->bt_ncand = 3; }
+    }
   }
   fill_mode_stats(ctx);
   ctx->h_partial = ctx->h_out;
@@ -803,7 +785,6 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.phase, P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[0], P))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.list[1], P))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->gs.pending, P))) return rc;
 
   const size_t S = P * kMaxSlots;
   if ((rc = dev_alloc(ctx, &ctx->gs.solve, S))) return rc;
@@ -814,12 +795,6 @@ int alloc_point_buffers(svsdf_ctx *ctx, size_t P) {
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_k, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_sdf, S))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->gs.sq_t, S))) return rc;
-  if (ctx->persistent) {   // task rings of k_gsip: zero = free slot (the kernel leaves them zeroed)
-    const size_t R = 2 * S + (size_t)kMaxBatches * kMaxShards * kShardSlack;
-    if ((rc = dev_alloc(ctx, &ctx->gs.q, R))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->gs.qsh, (size_t)kMaxBatches * kMaxShards))) return rc;
-    HIPCHK(hipMemsetAsync(ctx->gs.q, 0, R * sizeof(unsigned long long), ctx->stream));
-  }
   return SVSDF_OK;
 }
 
@@ -1034,6 +1009,7 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   // fewer lanes.  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
   ctx->have_prev_nsolve = false;
   ctx->ub_tune = 0;
+  ctx->bt_state = 0;
   ctx->ub_ratio = 0.0;
   if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; }
   if (!ctx->G_env) {
@@ -1152,6 +1128,9 @@ void merge_stats(svsdf_ctx *ctx) {
     const svsdf_stats &a = s->stats;
     t.points += a.points; t.interior_points += a.interior_points; t.solves += a.solves;
     t.gsip_samples += a.gsip_samples; t.sdf_evals += a.sdf_evals; t.scan_evals += a.scan_evals;
+    t.round_scan_evals += a.round_scan_evals;
+    t.round_ms = std::max(t.round_ms, a.round_ms); t.round_ms_sum = std::max(t.round_ms_sum, a.round_ms_sum);
+    t.batches = std::max(t.batches, a.batches);
     t.culled_points += a.culled_points;
     t.device_ms = std::max(t.device_ms, a.device_ms); t.solve_ms = std::max(t.solve_ms, a.solve_ms);
     t.solve_ms_sum = std::max(t.solve_ms_sum, a.solve_ms_sum);
@@ -1162,7 +1141,8 @@ void merge_stats(svsdf_ctx *ctx) {
     t.bound_ratio = std::max(t.bound_ratio, a.bound_ratio);
   }
   t.bound_mode_decided = 1;
-  for (svsdf_ctx *s : ctx->subs) t.bound_mode_decided &= s->stats.bound_mode_decided;
+  t.plan_settled = 1;
+  for (svsdf_ctx *s : ctx->subs) { t.bound_mode_decided &= s->stats.bound_mode_decided; t.plan_settled &= s->stats.plan_settled; }
   t.n_devices = (int)ctx->subs.size();
   t.combine = ctx->combine;
   t.combine_ms = ctx->combine_ms;
@@ -1177,14 +1157,19 @@ int run_pipeline_group(svsdf_ctx *ctx, int N, const double *coeffs, const double
   int rc = group_run(ctx, [&](int k) -> int {
     svsdf_ctx *s = ctx->subs[k];
     int r = run_pipeline_leaf(s, N, coeffs, T);
-    if (r || !rccl) return r;
-    // all-reduce of the (19N+1)-double partial over the in-process communicator, on the device's own stream
+    if (!rccl) return r;
+    // EVERY device thread joins the collective, also after a local failure (non-finite result, exhausted GSIP
+    // iterations, invalid trajectory ...): a thread that returned early would leave the others blocked in the all-reduce
+    // for ever.  A failed stripe contributes a NaN-poisoned partial (all bits set), so no rank can mistake the sum for a
+    // result; the error is reported after the synchronisation.
+    (void)hipSetDevice(s->device);
+    if (r) (void)hipMemsetAsync(s->d_out, 0xFF, plen * sizeof(double), s->stream);
     const int e = g_rccl.AllReduce(s->d_out, ctx->d_red[k], plen, kNcclFloat64, kNcclSum, ctx->comms[k], s->stream);
-    if (e) return fail(s, SVSDF_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
-    if (k == 0 && hipMemcpyAsync(ctx->h_red, ctx->d_red[0], plen * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess)
-      return fail(s, SVSDF_ERR_RCCL, "read-back of the reduced partial failed");
-    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(s, SVSDF_ERR_RCCL, "stream sync after ncclAllReduce failed");
-    return SVSDF_OK;
+    if (e && !r) r = fail(s, SVSDF_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
+    if (k == 0 && hipMemcpyAsync(ctx->h_red, ctx->d_red[0], plen * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess && !r)
+      r = fail(s, SVSDF_ERR_RCCL, "read-back of the reduced partial failed");
+    if (hipStreamSynchronize(s->stream) != hipSuccess && !r) r = fail(s, SVSDF_ERR_RCCL, "stream sync after ncclAllReduce failed");
+    return r;
   });
   if (rc) return rc;
   const auto t0 = std::chrono::steady_clock::now();
@@ -1365,13 +1350,6 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     h->host_only = true;
     return h;
   }
-  // Large shards run as 4 point batches on their own streams plus the main stream; the HIP runtime maps streams onto
-  // GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue serialise (measured with the runtime
-  // bundled with PyTorch-ROCm 7.0: 4 batches 10.2 ms vs 8.7 ms with 8 queues).  Only effective if the runtime has not
-  // been initialised yet by the host process (a Python host sets it before importing torch, see bench.py); never
-  // overrides a value the user chose.
-  static const int queues_hint = setenv("GPU_MAX_HW_QUEUES", "8", 0);
-  (void)queues_hint;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_last_error = "svsdf_create: no HIP device (this library has no CPU fallback)";
@@ -1411,7 +1389,6 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   sp.nverts = 0;
   sp.accel = nullptr;
   sp.edges = nullptr;
-  sp.edges_lds = 0;
   if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
     std::vector<double> &v = ctx->poly_xy;
     if (cfg->polygon_xy && cfg->polygon_nverts >= 3) {
@@ -1446,9 +1423,9 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     sp.nverts = (int)(v.size() / 2);
     sp.accel = reinterpret_cast<const PolyAccel *>(ctx->d_poly);
     sp.edges = pa.hdr.edges;
-    // the solve / round kernels keep outlines of up to 512 edges (20 KB) in LDS next to the pose table
-    sp.edges_lds = (sp.nverts <= 512) ? 1 : 0;
-    if (const char *e = std::getenv("SVSDF_POLY_LDS")) sp.edges_lds = std::atoi(e) != 0 && sp.nverts <= 2048;
+    // the solve / round kernels keep outlines of up to 1024 edges (40 KB) in LDS in front of the pose table
+    ctx->poly_lds = sp.nverts <= kPolyLdsMaxVerts;
+    if (const char *e = std::getenv("SVSDF_POLY_LDS")) ctx->poly_lds = ctx->poly_lds && std::atoi(e) != 0;
     ctx->cfg.polygon_nverts = sp.nverts;
   }
   ctx->G_env = 0;
@@ -1461,13 +1438,10 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) { ctx->delta_all_iter = std::atoi(e); ctx->all_iter_env = true; }
   if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) { ctx->select_delta = std::atof(e); ctx->select_env = true; }
-  if (const char *e = std::getenv("SVSDF_PERSISTENT")) ctx->persistent = std::atoi(e) != 0;
   {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n > 0) ctx->n_cu = n;
   }
-  if (const char *e = std::getenv("SVSDF_GSIP_GRACE")) ctx->gsip_grace = std::atoi(e);
-  if (const char *e = std::getenv("SVSDF_PERSISTENT_FROM")) ctx->gsip_from = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
@@ -1539,7 +1513,7 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->gs.pt,
                   ctx->gs.r, ctx->gs.theta0, ctx->gs.theta_res, ctx->gs.iter, ctx->gs.nsamp, ctx->gs.phase,
                   ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
-                  ctx->gs.sq_ub, ctx->gs.sq_k, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->gs.pending, ctx->gs.q, ctx->gs.qsh, ctx->d_ctl,
+                  ctx->gs.sq_ub, ctx->gs.sq_k, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl,
                   ctx->d_block_partials, ctx->d_sums,
                   ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_flag};
   for (void *p : bufs)

@@ -62,7 +62,8 @@ constexpr int kChunk = 8;
 struct Chunk { double cx, cy, rb, slack; };  // slack: continuous-path allowance V_c * h for the exact cull (host)
 
 constexpr int kStatSlots = 32;
-struct StatSlot { unsigned long long solves, evals, scan, culled, pad[12]; };   // one 128-byte line
+struct StatSlot { unsigned long long solves, evals, scan, culled, round_scan, pad[11]; };   // one 128-byte line
+// (solves / evals / scan / culled: k_solve; round_scan: table evaluations of k_round's seed scans)
 __device__ __forceinline__ StatSlot *stat_slot(StatSlot *slots) {
   return slots + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (kStatSlots - 1));
 }
@@ -76,8 +77,6 @@ struct BatchCtl {
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
   int pad;
-  unsigned q_done;   // persistent GSIP kernel (k_gsip): points finished, handed in by the waves as they run dry
-  int q_error;       // k_gsip gave up (2 ring full, 3 poll cap, 4 round without samples): the host falls back to the chain
   // work counters (statistics), added to by every wave at the end of a launch: one address takes ~80 M atomics / s
   // (tools/experiments/coh_latency.hip), a full grid of waves ending together would queue up behind four words of one
   // cache line -- the waves spread over kStatSlots lines, k_finish adds them up
@@ -107,17 +106,14 @@ __device__ __forceinline__ TrajL stage_traj(const TrajDev *__restrict__ g, doubl
   return tr;
 }
 
-// Polygon: copy the outline's edges (5 doubles each) behind the other LDS tables of the block and point sp at the copy;
-// call before the block's __syncthreads.  lds_doubles(n) = 5 n when the host asked for it (sp.edges_lds), else 0.
-__host__ __device__ __forceinline__ size_t poly_lds_doubles(int nverts, int edges_lds) { return edges_lds ? 5 * (size_t)nverts : 0; }
+// kPolygonLds kernels: copy the outline's edges (5 doubles each) to the START of the block's dynamic LDS (shape_sdf reads
+// them from there, svsdf_shapes.hpp); the kernel's other LDS tables follow at poly_lds_doubles<SHAPE>(nverts).  Call
+// before the block's first __syncthreads.
 template <int SHAPE>
-__device__ __forceinline__ void stage_poly_edges(ShapeParams &sp, double *lds) {
-  if constexpr (SHAPE == kPolygon) {
-    if (sp.edges_lds) {
-      const double *src = reinterpret_cast<const double *>(sp.edges);
-      for (int i = threadIdx.x; i < 5 * sp.nverts; i += blockDim.x) lds[i] = src[i];
-      sp.edges = reinterpret_cast<const PolyEdge *>(lds);
-    }
+__device__ __forceinline__ void stage_poly_edges(const ShapeParams &sp, double *lds) {
+  if constexpr (SHAPE == kPolygonLds) {
+    const double *src = reinterpret_cast<const double *>(sp.edges);
+    for (int i = threadIdx.x; i < 5 * sp.nverts; i += blockDim.x) lds[i] = src[i];
   }
 }
 
@@ -352,12 +348,10 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     for (int r = 0; r < kMaxIter + 2; ++r) { c.n_active[r] = 0; c.n_solve[r] = 0; c.n_seed[r] = 0; }
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
     c.nonfinite = 0;
-    c.q_done = 0u;
-    c.q_error = 0;
   }
   for (int i = threadIdx.x; i < nbatch * kStatSlots; i += blockDim.x) {
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
-    ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull;
+    ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull; ss.round_scan = 0ull;
   }
   if (threadIdx.x == 0) {
     tr->N = N; tr->K = K; tr->dur = dur; tr->exact = exact;
@@ -627,7 +621,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
 
 // Layers 2-4 of choiceTInit (SWM:557-577) + gradientDescent (SWM:1249-1325) for ONE query by G cooperating lanes,
 // from the layer-1 seed (time tk[best_k], value best_d): the argmin time x and its value fx (all lanes of the group get
-// them).  Shared by k_solve and the persistent GSIP kernel.
+// them).
 template <int SHAPE, int G, int U>
 __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
                                                   double px, double py, int best_k, double best_d, double &x_out,
@@ -765,7 +759,7 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
 //    accepts (bit-identical result, shorter dependent chain).  getSDF_DOT (SWM:799-806) is
 //    evaluated once per descent pass: x does not change inside the ladder, so the reference's
 //    per-trial re-evaluation returns the same number.
-// LDS: [pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
+// LDS: [Polygon edges 5 nverts (kPolygonLds only) | pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
 // ---------------------------------------------------------------------------------------------
 template <int SHAPE, int G, int U>
 __global__ void __launch_bounds__(kBlock, SVSDF_SOLVE_WAVES)
@@ -778,16 +772,17 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
-  stage_poly_edges<SHAPE>(sp, solve_lds + 4 * (size_t)K + 4 * (size_t)nch + (size_t)traj_lds_doubles(trg->N));
-  Pose *pose = reinterpret_cast<Pose *>(solve_lds);
-  Chunk *chunks = reinterpret_cast<Chunk *>(solve_lds + 4 * (size_t)K);
+  stage_poly_edges<SHAPE>(sp, solve_lds);
+  double *tab_lds = solve_lds + poly_lds_doubles<SHAPE>(sp.nverts);
+  Pose *pose = reinterpret_cast<Pose *>(tab_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(tab_lds + 4 * (size_t)K);
   {
     const double *src = reinterpret_cast<const double *>(pose_g);
-    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) solve_lds[i] = src[i];
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) tab_lds[i] = src[i];
     const double *srcc = reinterpret_cast<const double *>(chunks_g);
-    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) solve_lds[4 * (size_t)K + i] = srcc[i];
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) tab_lds[4 * (size_t)K + i] = srcc[i];
   }
-  const TrajL tr = stage_traj(trg, solve_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
+  const TrajL tr = stage_traj(trg, tab_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
   const int li = Grp<G>::li();
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0;
   // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
@@ -858,18 +853,6 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 #define SVSDF_LAZY_REPS 2   // scan passes of the lazy bound mode: the band, then its extension (a third changes nothing)
 #endif
 enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
-// one shard of the persistent GSIP kernel's task queue (k_gsip), in its own cache line
-struct QShard { unsigned head, reserve, stop, pad[29]; };
-constexpr int kMaxShards = 256;
-constexpr unsigned kShardSlack = 2048;
-// ring slots per shard: twice an even share of the tasks that can be outstanding (kMaxSlots per point) plus a slack
-__host__ __device__ __forceinline__ unsigned gsip_shard_slots(int count, int nq) {
-  return (unsigned)((2ull * (unsigned long long)count * kMaxSlots) / (unsigned long long)nq) + kShardSlack;
-}
-// ring slots of a batch (any shard count)
-__host__ __device__ __forceinline__ size_t gsip_ring_slots(size_t count) {
-  return 2 * count * kMaxSlots + (size_t)kMaxShards * kShardSlack;
-}
 struct GsipState {
   int *pt;          // index of the (sorted) main point
   double *r;        // current circle radius
@@ -883,10 +866,6 @@ struct GsipState {
   // sample slots [j * stride + batch start + a]
   double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
   int *sq_k;        // layer-1 seed index of the sample (full-scan mode: sq_ub is then the seed value)
-  int *pending;     // per interior point: solves of the current round still outstanding (persistent GSIP kernel)
-  unsigned long long *q;   // task rings of the persistent GSIP kernel (this batch's shards one after the other), all zero
-                           // between evaluations
-  QShard *qsh;             // this batch's queue shards
 };
 
 // Per main point after the first solve: exterior -> FD gradient (getGradPrelAtTimeStamp,
@@ -972,22 +951,8 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
 // One GSIP step of ONE interior point (index a of its batch) by its LP lanes: close the round whose samples were solved
 // (or request supplementary solves), write the result when the point is finished, or open the next round (samples,
 // bounds, selection).  Outputs: which of this lane's samples are to be solved (list_me / mlist: per pass, the mask over
-// the point's lanes), whether the point stays active (push_next), samples emitted (n_emit), finished.  Shared by k_round
-// (one launch per GSIP iteration) and the persistent GSIP kernel (one ROUND task).
-// Global accesses of state that OTHER waves of the same launch write (persistent GSIP kernel only, COH = true): relaxed
-// agent-scope atomics, i.e. loads that do not hit a stale line of this XCD's L2 and write-through stores -- with these the
-// hand-overs need no cache-wide write-back / invalidate (an agent-scope fence costs tens of microseconds when thousands of
-// waves issue them), only the wave's own completion counter (workgroup-scope fence).  COH = false: plain accesses.
-template <bool COH, typename T>
-__device__ __forceinline__ T gld(const T *p) {
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <bool COH, typename T>
-__device__ __forceinline__ void gst(T *p, T v) {
-  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
+// the point's lanes), whether the point stays active (push_next), samples emitted (n_emit), finished.  Called by k_round
+// (one launch per GSIP iteration).
 template <int NP>
 struct RoundOut {
   bool list_me[NP];
@@ -995,7 +960,7 @@ struct RoundOut {
   int n_emit;
   bool push_next, finished;
 };
-template <int SHAPE, int LP, int MODE, bool COH = false>
+template <int SHAPE, int LP, int MODE>
 __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *pose, const Chunk *chunks, int K, int nch,
                                             const double *__restrict__ px_, const double *__restrict__ py_,
                                             const GsipState &gs, size_t stride, int start, int a, double delta,
@@ -1022,18 +987,18 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
     ia = (size_t)start + a;
     i = gs.pt[ia];
     cx = px_[i]; cy = py_[i];
-    r = gld<COH>(&gs.r[ia]); theta0 = gld<COH>(&gs.theta0[ia]); theta_res = gld<COH>(&gs.theta_res[ia]);
-    open = gld<COH>(&gs.phase[ia]) == kPhaseNew;
+    r = gs.r[ia]; theta0 = gs.theta0[ia]; theta_res = gs.theta_res[ia];
+    open = gs.phase[ia] == kPhaseNew;
     if (!open) {
       // ---- close the round: max over the solved samples, first index wins ties (strict >)
-      const int n = gld<COH>(&gs.nsamp[ia]);
+      const int n = gs.nsamp[ia];
       double g_mine[NP];
       double g = kUnsolved;
       int idx = 0x7fffffff;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        g_mine[ps] = (j < n) ? gld<COH>(&gs.sq_sdf[(size_t)j * stride + ia]) : kUnsolved;
+        g_mine[ps] = (j < n) ? gs.sq_sdf[(size_t)j * stride + ia] : kUnsolved;
         if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
       }
       {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
@@ -1046,26 +1011,26 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           step(Grp<LP>::template xchg<4>(g), Grp<LP>::template xchg<4>(idx));
         }
       }
-      double max_g = -100000, real_t = gld<COH>(&res_t[i]), star_th = 0.0;
+      double max_g = -100000, real_t = res_t[i], star_th = 0.0;
       if (g > max_g) {
         const size_t sb = (size_t)idx * stride + ia;
-        max_g = g; real_t = gld<COH>(&gs.sq_t[sb]); star_th = gld<COH>(&gs.sqth[sb]);
+        max_g = g; real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
       }
       // unsolved samples that could still reach max_g -> supplementary solves
       bool any = false;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gld<COH>(&gs.sq_ub[(size_t)j * stride + ia]) >= max_g;
+        list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gs.sq_ub[(size_t)j * stride + ia] >= max_g;
         mlist[ps] = ballot_g(list_me[ps]);
         any = any || (mlist[ps] != 0u);
       }
       if (any) {
         push_next = true;
-        if (l == 0) gst<COH>(&gs.phase[ia], (int)kPhaseSupp);
+        if (l == 0) gs.phase[ia] = (int)kPhaseSupp;
       } else {
         const double r_star = r - max_g;
-        const int iter = gld<COH>(&gs.iter[ia]);
+        const int iter = gs.iter[ia];
         if (iter > 8 || fabs(max_g) < 0.1) {
           if (l == 0) {
             const double corx = cx + 1.0 * r_star * cos(star_th);
@@ -1083,9 +1048,9 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           r = r_star;
           theta0 = star_th;
           if (l == 0) {
-            gst<COH>(&gs.r[ia], r); gst<COH>(&gs.theta_res[ia], theta_res); gst<COH>(&gs.theta0[ia], theta0);
-            gst<COH>(&gs.iter[ia], iter + 1);
-            gst<COH>(&res_t[i], real_t);
+            gs.r[ia] = r; gs.theta_res[ia] = theta_res; gs.theta0[ia] = theta0;
+            gs.iter[ia] = iter + 1;
+            res_t[i] = real_t;
           }
           open = true;
         }
@@ -1126,9 +1091,9 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             const int k1 = (c0 * kChunk + kChunk < K) ? c0 * kChunk + kChunk : K;
             for (int k = c0 * kChunk; k < k1; ++k) u = dmin(u, sdf_from_pose<SHAPE>(sp, pose[k], qx, qy));
             ub[ps] = u;
-            gst<COH>(&gs.sq_ub[s], u);
+            gs.sq_ub[s] = u;
           }
-          gst<COH>(&gs.sqx[s], qx); gst<COH>(&gs.sqy[s], qy); gst<COH>(&gs.sqth[s], theta); gst<COH>(&gs.sq_sdf[s], kUnsolved);
+          gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_sdf[s] = kUnsolved;
         }
         if (ps + 1 < NP) {
 #pragma unroll
@@ -1168,8 +1133,8 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         for (int ps = 0; ps < NP; ++ps)
           if (valid[ps]) {
             const size_t s = (size_t)(l + LP * ps) * stride + ia;
-            gst<COH>(&gs.sq_ub[s], ub[ps]);
-            gst<COH>(&gs.sq_k[s], kk[ps]);
+            gs.sq_ub[s] = ub[ps];
+            gs.sq_k[s] = kk[ps];
           }
       }
       if constexpr (MODE == 2) {
@@ -1258,8 +1223,8 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         for (int ps = 0; ps < NP; ++ps)
           if (valid[ps]) {
             const size_t s = (size_t)(l + LP * ps) * stride + ia;
-            gst<COH>(&gs.sq_ub[s], ub[ps]);
-            gst<COH>(&gs.sq_k[s], kk[ps]);
+            gs.sq_ub[s] = ub[ps];
+            gs.sq_k[s] = kk[ps];
             if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
           }
       }
@@ -1278,7 +1243,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         mlist[ps] = ballot_g(list_me[ps]);
       }
       push_next = true;
-      if (l == 0) { gst<COH>(&gs.nsamp[ia], n_emit); gst<COH>(&gs.phase[ia], (int)kPhaseEval); }
+      if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = (int)kPhaseEval; }
     }
   }
 
@@ -1307,14 +1272,15 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
-  Pose *pose = reinterpret_cast<Pose *>(round_lds);
-  Chunk *chunks = reinterpret_cast<Chunk *>(round_lds + 4 * (size_t)K);
-  stage_poly_edges<SHAPE>(sp, round_lds + 4 * (size_t)K + 4 * (size_t)nch);
+  stage_poly_edges<SHAPE>(sp, round_lds);
+  double *tab_lds = round_lds + poly_lds_doubles<SHAPE>(sp.nverts);
+  Pose *pose = reinterpret_cast<Pose *>(tab_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(tab_lds + 4 * (size_t)K);
   {
     const double *src = reinterpret_cast<const double *>(pose_g);
-    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) round_lds[i] = src[i];
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) tab_lds[i] = src[i];
     const double *srcc = reinterpret_cast<const double *>(chunks_g);
-    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) round_lds[4 * (size_t)K + i] = srcc[i];
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) tab_lds[4 * (size_t)K + i] = srcc[i];
   }
   __syncthreads();
   const int start = ctl->start;
@@ -1380,7 +1346,6 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     }
     if (push_next && l == 0) {
       nxt[s_base[1][hw]] = a;
-      gs.pending[ia] = n_list;   // solves outstanding for this point (read by the persistent GSIP kernel only)
     }
     __syncthreads();
   }
@@ -1390,309 +1355,8 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     for (int m = 32; m >= 1; m >>= 1) tc += __shfl_xor(tc, m, 64);
     if ((threadIdx.x & 63) == 0 && tc) {
       StatSlot *ss = stat_slot(ctl->stat);
-      atomicAdd(&ss->scan, tc); atomicAdd(&ss->evals, tc);
+      atomicAdd(&ss->round_scan, tc);
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_gsip: the whole GSIP loop of a batch in ONE persistent launch (experimental, env SVSDF_PERSISTENT=1).
-//
-// After k_round(it0) (it0 = 0: right after round 1 of every interior point was opened; it0 > 0: the first it0 iterations
-// run as launches, the sparsely populated rest here) the chain  k_solve(i) -> k_round(i+1)  (~10 dependent launch pairs,
-// each with a ramp-up and a tail, every point waiting for the slowest one of its iteration) is replaced by task queues
-// in device memory served by persistent waves:
-//   SOLVE task (payload = sample slot >= 0): layer-1 scan unless seeded, layers 2-4, descent (descend_from_seed); the
-//                solve that brings its point's `pending` counter to zero queues the point's ROUND task
-//   ROUND task (payload = -2 - interior index): 32 lanes, round_point -- close / supplementary / finish / open -- and
-//                the SOLVE tasks it requests (pending = their number)
-// so a point advances as soon as ITS solves are done.
-//
-// Queues.  One address takes ~80 M atomics per second on this part (tools/experiments/coh_latency.hip: 37 us per
-// returning atomicAdd when 3072 waves share one counter, 0.4 us when they do not), and an evaluation at 1 M points moves
-// ~3 M tasks: a single queue is bound by its two cursors.  So there are nq (<= 256) queue shards, each with its own
-// cursors in its own cache line and its own ring; a wave consumes from its home shard (wave id mod nq: ~12 waves per
-// shard) and pushes what it produces to the shards in rotation.  Within a shard: positions 0, 1, 2, ... handed out by two
-// fetch-adds -- producers reserve at `reserve`, consumers take tickets at `head` (tickets may run ahead of the
-// reservations: an idle wave then waits on its own positions, no shared word is polled).  Position p lives in ring slot
-// p % Qs as (p + 1) << 32 | payload: the tag says the entry is the one the ticket is for, the consumer zeroes the slot when
-// it takes the entry, a producer only writes a zero slot (the rings hold twice the tasks that can be outstanding plus a
-// slack, so it never waits in practice).  k_round(0)'s solve list is dealt out statically, 16 entries per wave and turn.
-// A ticket is as many positions as the shard has unclaimed reservations -- 16, 8, 4 (SOLVE: 4, 8, 16 lanes per task) --
-// and 2 when there are fewer (32 lanes per task, the chain's late-iteration width: the critical path of the tail); any
-// width gives the same bits.  Everything one wave hands to another (possibly on a different XCD) goes through coherent
-// accesses (gld / gst), ordered by the wave's own completion counters: no cache-wide fences (94 us each under load).
-// End: waves count the points they finished and add them to ctl->q_done when they run dry; the wave that completes the
-// count raises every shard's stop word.  Same arithmetic per point as the chain (round_point, descend_from_seed): same
-// results.  A spin cap raises q_error and the host reruns the evaluation through the launch chain.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned q_load(const unsigned *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long q_peek(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// publish payload at position pos (the data it refers to is already written and complete)
-__device__ __forceinline__ bool q_put(unsigned long long *ring, unsigned Q, unsigned pos, int payload) {
-  unsigned long long *slot = ring + (pos % Q);
-  for (int spin = 0; q_peek(slot) != 0ull; ++spin) {   // previous lap not taken yet: the ring is sized so that this never waits
-    if (spin > (1 << 20)) return false;
-    __builtin_amdgcn_s_sleep(2);
-  }
-  __hip_atomic_store(slot, ((unsigned long long)(pos + 1u) << 32) | (unsigned long long)(unsigned)payload, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
-
-// SOLVE tasks of a ticket by G lanes each (lane group g <-> ticket entry g): solve, store, count down the point's
-// `pending`; returns (leader lane of the group) whether this was the point's last solve and the point's index
-template <int SHAPE, int MODE, int G>
-__device__ __forceinline__ void gsip_solve(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
-                                           const Pose *pose, const Chunk *chunks, int K, int nch, const GsipState &gs,
-                                           size_t stride, int start, bool live, int payload, bool &last, int &a_done,
-                                           unsigned &n_eval, unsigned &n_scan, unsigned &n_solved) {
-  last = false;
-  a_done = 0;
-  if (!live) return;
-  const size_t slot = (size_t)payload;
-  const double qx = gld<true>(&gs.sqx[slot]), qy = gld<true>(&gs.sqy[slot]);
-  double best_d = 1e9, x = 0.0, fx = 0.0;
-  int best_k = -1;
-  if constexpr (MODE != 0) { best_k = gld<true>(&gs.sq_k[slot]); best_d = gld<true>(&gs.sq_ub[slot]); }
-  if (best_k < 0) {
-    bool culled;
-    scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), best_d, best_k,
-                          culled, n_scan);
-  }
-  descend_from_seed<SHAPE, G, 1>(tr, tk, sp, qx, qy, best_k, best_d, x, fx, n_eval);
-  if (Grp<G>::li() == 0) {
-    gst<true>(&gs.sq_sdf[slot], fx);
-    gst<true>(&gs.sq_t[slot], x);
-    ++n_solved;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the solved value is out before the counter moves
-    const size_t ia = slot % stride;
-    last = atomicSub(&gs.pending[ia], 1) == 1;
-    a_done = (int)(ia - (size_t)start);
-  }
-}
-
-#ifndef SVSDF_GSIP_WAVES
-#define SVSDF_GSIP_WAVES 3   // waves per SIMD the register allocation aims at (k_solve's 146 VGPRs give 3 as well)
-#endif
-template <int SHAPE, int MODE>
-__global__ void __launch_bounds__(kBlock, SVSDF_GSIP_WAVES)
-k_gsip(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
-       const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_, const double *__restrict__ py_,
-       GsipState gs, size_t stride, double sel_delta, double sel_band, int all_round, int grace, int nq, int it0,
-       double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
-       BatchCtl *__restrict__ ctl) {
-  constexpr int LP = 32;
-  extern __shared__ double gsip_lds[];
-  // the launch takes over after k_round(it0): the points that round kept active, the solves it requested
-  const int n_int = ctl->n_active[it0 + 1];
-  if (n_int <= 0) return;
-  const int K = trg->K;
-  const int nch = (K + kChunk - 1) / kChunk;
-  Pose *pose = reinterpret_cast<Pose *>(gsip_lds);
-  Chunk *chunks = reinterpret_cast<Chunk *>(gsip_lds + 4 * (size_t)K);
-  {
-    const double *src = reinterpret_cast<const double *>(pose_g);
-    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) gsip_lds[i] = src[i];
-    const double *srcc = reinterpret_cast<const double *>(chunks_g);
-    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) gsip_lds[4 * (size_t)K + i] = srcc[i];
-  }
-  const TrajL tr = stage_traj(trg, gsip_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
-  const int start = ctl->start, count = ctl->count;
-  const unsigned n0 = (unsigned)ctl->n_solve[it0];        // k_round(it0)'s solve list
-  const int *list0 = gs.solve + (size_t)start * kMaxSlots;
-  const unsigned Qs = gsip_shard_slots(count, nq);        // ring slots per shard
-  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-  const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const unsigned home_s = wave_id & (unsigned)(nq - 1);
-  QShard *home = gs.qsh + home_s;
-  unsigned long long *home_ring = gs.q + (size_t)home_s * Qs;
-  unsigned rr = wave_id * 40503u;                         // rotation of the shards this wave pushes to
-  unsigned c0 = wave_id;                                  // next 16-entry chunk of the initial list
-  const int lane = (int)(threadIdx.x & 63);
-  const int hw = lane / LP, l = lane & (LP - 1);
-  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_emit_tot = 0;
-  unsigned my_done = 0;                                   // lane 0: points this wave finished since its last flush
-  bool quit = false;
-  // an error: record it and stop every wave (the host falls back to the launch chain)
-  auto raise = [&](int code) {
-    atomicExch(&ctl->q_error, code);
-    for (int s = 0; s < nq; ++s) gst<true>(&gs.qsh[s].stop, 1u);
-  };
-  while (!quit) {
-    // ---------------- the next entries: a chunk of the initial list, else a ticket of the home shard -- as many
-    // positions as the shard has reserved tasks nobody holds a ticket for (16, 8, 4; their entries are on their way),
-    // 2 when there are fewer (the shard's waves are not all busy: the widest lane groups, the shortest chain)
-    unsigned t0 = 0;
-    int tn = 16;
-    const bool from_list = c0 * 16u < n0;
-    if (from_list) {
-      t0 = c0 * 16u;
-      c0 += n_waves;
-    } else {
-      if (lane == 0) {
-        const int backlog = (int)(q_load(&home->reserve) - q_load(&home->head));
-        tn = (backlog >= 16) ? 16 : (backlog >= 8) ? 8 : (backlog >= 4) ? 4 : 2;
-        t0 = atomicAdd(&home->head, (unsigned)tn);
-      }
-      tn = __builtin_amdgcn_readfirstlane(tn);
-      t0 = __builtin_amdgcn_readfirstlane(t0);
-    }
-    const int gl = 64 / tn;                   // lanes per entry
-    const int e = lane / gl;                  // this lane's entry
-    const bool leader = (lane % gl) == 0;
-    const unsigned pos = t0 + (unsigned)e;
-    unsigned todo = (1u << tn) - 1u;          // entries not processed yet (wave-uniform)
-    if (from_list && t0 + 16u > n0) todo = (1u << (n0 - t0)) - 1u;
-    int polls = 0, waited = 0;
-    bool have = false;                        // leader lanes: entry taken from the ring, not processed yet
-    int payload = 0;
-    while (todo) {
-      // ---------------- poll the entries' slots
-      if (leader && ((todo >> e) & 1u) && !have) {
-        if (from_list) {
-          have = true;
-          payload = list0[pos];
-        } else {
-          unsigned long long *slot = home_ring + (pos % Qs);
-          const unsigned long long v = q_peek(slot);
-          if ((unsigned)(v >> 32) == pos + 1u) {
-            have = true;
-            payload = (int)(unsigned)(v & 0xffffffffull);
-            __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // taken
-          }
-        }
-      }
-      const unsigned long long hm = __ballot(have);
-      // a ticket of 4+ positions was sized by reservations: its entries arrive within microseconds of each other, and a
-      // pass costs the same for 3 entries as for 16 -- wait (a bounded while) for the ticket to be complete
-      if (hm != 0ull && tn > 2 && waited < grace && (unsigned)__popcll(hm) < (unsigned)__popc(todo)) {
-        ++waited;
-        __builtin_amdgcn_s_sleep(4);
-        continue;
-      }
-      if (hm == 0ull) {
-        ++polls;
-        int stop = 0;
-        if (lane == 0) {
-          if (polls == 1 && my_done > 0u) {   // run dry: hand in the finished points; the last one ends the launch
-            const unsigned before = atomicAdd(&ctl->q_done, my_done);
-            if (before + my_done >= (unsigned)n_int) stop = 2;
-            my_done = 0u;
-          }
-          if (!stop && q_load(&home->stop) != 0u) stop = 1;
-        }
-        stop = __builtin_amdgcn_readfirstlane(stop);
-        if (stop == 2)
-          for (int s = lane; s < nq; s += 64) gst<true>(&gs.qsh[s].stop, 1u);
-        if (stop) { quit = true; break; }
-        if (polls > (1 << 21)) {   // ~ seconds without a task and without the end: give up loudly
-          if (lane == 0) raise(3);
-          quit = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        continue;
-      }
-      polls = 0;
-      unsigned got = 0u;   // entries taken in this pass
-      for (unsigned long long m = hm; m; m &= m - 1ull) got |= 1u << ((__ffsll((long long)m) - 1) / gl);
-      todo &= ~got;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the entries' data is read after the entries (coherent loads)
-      // every lane of an entry's group learns its payload
-      const int pl = __shfl(payload, e * gl, 64);
-      const bool mine = (got >> e) & 1u;
-      have = false;
-      // ---------------- SOLVE entries, one lane group each
-      bool last = false;
-      int a_done = 0;
-      if (tn == 16)
-        gsip_solve<SHAPE, MODE, 4>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
-                                   n_eval, n_scan, n_solved);
-      else if (tn == 8)
-        gsip_solve<SHAPE, MODE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
-                                   n_eval, n_scan, n_solved);
-      else if (tn == 4)
-        gsip_solve<SHAPE, MODE, 16>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
-                                    n_eval, n_scan, n_solved);
-      else
-        gsip_solve<SHAPE, MODE, 32>(tr, tk, sp, pose, chunks, K, nch, gs, stride, start, mine && pl >= 0, pl, last, a_done,
-                                    n_eval, n_scan, n_solved);
-      {  // the points whose last solve this was: their ROUND tasks, one reservation per wave
-        const unsigned long long lm = __ballot(last);
-        if (lm) {
-          const int cnt = __popcll(lm);
-          const unsigned ts = (rr++) & (unsigned)(nq - 1);
-          unsigned rp = 0;
-          if (lane == 0) rp = atomicAdd(&gs.qsh[ts].reserve, (unsigned)cnt);
-          rp = __builtin_amdgcn_readfirstlane(rp);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (last && !q_put(gs.q + (size_t)ts * Qs, Qs, rp + (unsigned)__popcll(lm & ((1ull << lane) - 1ull)), -2 - a_done))
-            raise(2);
-        }
-      }
-      // ---------------- ROUND entries, two at a time (32 lanes each)
-      unsigned rmask = 0u;
-      {
-        const unsigned long long rm = __ballot(leader && mine && pl < 0);
-        for (unsigned long long m = rm; m; m &= m - 1ull) rmask |= 1u << ((__ffsll((long long)m) - 1) / gl);
-      }
-      while (rmask) {
-        const int e0 = __ffs(rmask) - 1;
-        rmask &= rmask - 1u;
-        int e1 = -1;
-        if (rmask) { e1 = __ffs(rmask) - 1; rmask &= rmask - 1u; }
-        const int my_e = hw == 0 ? e0 : e1;
-        const bool active = my_e >= 0;
-        const int pv = __shfl(payload, (active ? my_e : 0) * gl, 64);   // from the entry's leader lane (all lanes take part)
-        const int a = active ? -2 - pv : 0;
-        const size_t ia = (size_t)start + a;
-        RoundOut<1> ro;
-        ro.list_me[0] = false; ro.mlist[0] = 0u; ro.n_emit = 0; ro.push_next = false; ro.finished = false;
-        if (active) {
-          // late rounds request every sample (no supplementary hand-over); any selection gives the same result
-          const bool all = gld<true>(&gs.iter[ia]) >= all_round;
-          round_point<SHAPE, LP, MODE, true>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, all ? 1e300 : sel_delta,
-                                             all ? 1e300 : sel_band, res_sdf, res_t, res_gx, res_gy, n_scan, ro);
-        }
-        const int n_list = __popc(ro.mlist[0]);   // uniform over the point's lanes
-        if (active && l == 0) {
-          n_emit_tot += (unsigned)ro.n_emit;
-          if (ro.push_next && n_list == 0) raise(4);   // cannot happen: a round has >= 1 sample
-          if (n_list > 0) gst<true>(&gs.pending[ia], n_list);
-        }
-        // the wave's SOLVE requests: one reservation, the two points' entries one after the other
-        const int n_other = __shfl(n_list, lane ^ LP, 64);
-        const int n_wave = n_list + n_other;
-        if (n_wave > 0) {
-          const unsigned ts = (rr++) & (unsigned)(nq - 1);
-          unsigned sp0 = 0;
-          if (lane == 0) sp0 = atomicAdd(&gs.qsh[ts].reserve, (unsigned)n_wave);
-          sp0 = __builtin_amdgcn_readfirstlane(sp0);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // samples, bounds, point state, pending: written through
-          if (ro.list_me[0]) {
-            const unsigned at = sp0 + (unsigned)((hw == 0 ? 0 : n_other) + __popc(ro.mlist[0] & ((1u << l) - 1u)));
-            if (!q_put(gs.q + (size_t)ts * Qs, Qs, at, (int)((size_t)l * stride + ia))) raise(2);
-          }
-        }
-        const unsigned long long fin = __ballot(active && l == 0 && ro.finished);
-        if (lane == 0) my_done += (unsigned)__popcll(fin);
-      }
-    }
-  }
-  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tm = n_emit_tot;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tm += __shfl_xor(tm, m, 64);
-  }
-  if (lane == 0 && (te || tm)) {
-    StatSlot *ss = stat_slot(ctl->stat);
-    atomicAdd(&ss->evals, te); atomicAdd(&ss->solves, ts); atomicAdd(&ss->scan, tc);
-    if (tm) atomicAdd(&ctl->n_seed[it0 + 1], (int)tm);
   }
 }
 
@@ -1716,13 +1380,6 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
 }
 
 #ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_api.hip
-// queue cursors of a batch before its k_gsip launch
-__global__ void k_gsip_init(BatchCtl *__restrict__ ctl, QShard *__restrict__ shards) {
-  if (threadIdx.x == 0) { ctl->q_done = 0u; ctl->q_error = 0; }
-  QShard z{};
-  for (int s = threadIdx.x; s < kMaxShards; s += blockDim.x) shards[s] = z;
-}
-
 __global__ void __launch_bounds__(kBlock)
 k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
@@ -1848,11 +1505,11 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
   if (threadIdx.x == 0) {
     double suf = 0.0;
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
-    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0;
+    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0, rs = 0;
     for (int b = 0; b < nbatch; ++b) {
       for (int k = 0; k < kStatSlots; ++k) {
         const StatSlot &ss = ctl[b].stat[k];
-        so += ss.solves; ev += ss.evals; sc += ss.scan; cu += ss.culled;
+        so += ss.solves; ev += ss.evals; sc += ss.scan; cu += ss.culled; rs += ss.round_scan;
       }
       in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
       rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
@@ -1868,9 +1525,7 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
       for (int b = 0; b < nbatch; ++b) ns += (unsigned long long)ctl[b].n_solve[i];
       stats_out[9 + i] = ns;
     }
-    unsigned long long qe = 0;   // persistent GSIP kernel: non-zero = it gave up, the host reruns through the chain
-    for (int b = 0; b < nbatch; ++b) qe += (unsigned long long)(ctl[b].q_error != 0 ? ctl[b].q_error : 0);
-    stats_out[9 + kMaxIter] = qe;
+    stats_out[9 + kMaxIter] = rs;
   }
 }
 

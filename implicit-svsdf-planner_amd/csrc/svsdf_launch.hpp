@@ -21,13 +21,6 @@ struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
   const TrajDev *traj; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py; GsipState gs;
   size_t stride; int it; double delta, band_delta; double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl;
 };
-// arguments of k_gsip<SHAPE, MODE>; the launcher clamps the grid to what is resident at once (every queue shard needs a
-// running wave) -- *blocks_per_cu caches the occupancy query (0 = not asked yet) -- and derives the shard count from it
-struct GsipLaunch {
-  const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py;
-  GsipState gs; size_t stride; double sel_delta, sel_band; int all_round, grace, it0, n_cu; int *blocks_per_cu; double *res_sdf, *res_t, *res_gx, *res_gy;
-  BatchCtl *ctl;
-};
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
   const TrajDev *traj; ShapeParams sp; const double *px, *py, *sdf, *t; double *res_sdf, *res_t, *res_gx, *res_gy;
   GsipState gs; BatchCtl *ctl;
@@ -37,7 +30,6 @@ struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
 bool launch_k_solve(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a);
 bool launch_k_round(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a);
 bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a);
-bool launch_k_gsip(int shape, int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a);
 bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out);
 bool launch_k_subsw(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,
                     const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);
@@ -49,7 +41,6 @@ bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParam
   bool launch_k_solve_s##K(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a); \
   bool launch_k_round_s##K(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a);      \
   bool launch_k_classify_s##K(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a);                  \
-  bool launch_k_gsip_s##K(int shape, int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a); \
   bool launch_k_rbound_s##K(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out); \
   bool launch_k_subsw_s##K(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,    \
                            const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);         \

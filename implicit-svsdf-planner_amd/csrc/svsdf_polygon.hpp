@@ -36,7 +36,7 @@ struct PolyEdge { double sx, sy, vx, vy, vv; };   // start, v = end - start, v.s
 // A candidate list in one 32-byte record of 16-bit words: [0] = count; count <= 15: [1 .. count] = the edges, ascending;
 // count > 15: [1] | [2] << 16 = offset of the list in `over`.  One 32-byte load gives a query its whole list in registers
 // (the evaluation walks it with shifts: no dependent load per edge).
-struct alignas(32) PolyRec { unsigned long long q[4]; };
+struct alignas(32) PolyRec { unsigned w[8]; };
 constexpr int kPolyInline = 15;
 
 struct PolyLevel {
@@ -84,8 +84,7 @@ __host__ __device__ __forceinline__ bool poly_cross_ray(double s2x, double s2y, 
 __host__ __device__ __forceinline__ double poly_edge_d2(const PolyEdge &e, double x, double y, double &cx, double &cy) {
   const double wx = x - e.sx, wy = y - e.sy;
   double t = (wx * e.vx + wy * e.vy) / e.vv;
-  if (t < 0.0) t = 0.0;
-  else if (t > 1.0) t = 1.0;
+  t = (t < 0.0) ? 0.0 : ((t > 1.0) ? 1.0 : t);   // if (t < 0) t = 0; else if (t > 1) t = 1;  (a NaN stays a NaN)
   cx = e.sx + t * e.vx;
   cy = e.sy + t * e.vy;
   const double dx = x - cx, dy = y - cy;
@@ -99,22 +98,41 @@ __host__ __device__ __forceinline__ int poly_cell(const PolyLevel &lv, double x,
   return (int)fy * lv.nx + (int)fx;
 }
 
-// walk the candidate list of a record: f(edge index) in ascending order
-template <typename F>
-__host__ __device__ __forceinline__ void poly_for_each(const PolyRec &rec, const unsigned short *over, F &&f) {
-  unsigned long long q0 = rec.q[0], q1 = rec.q[1], q2 = rec.q[2], q3 = rec.q[3];
-  const unsigned cnt = (unsigned)(q0 & 0xffffull);
+// Walk the candidate list of a record in ascending order: f(edge index, edge, start of the next edge).  The list sits in
+// registers (shifted out 16 bits at a time) or, when longer than kPolyInline, in `over`; the edge of step k + 1 is
+// loaded while step k computes (the loop is a dependent chain of loads otherwise).  NEXT: also the following edge's
+// start = this edge's end (crossing test).
+template <bool NEXT, typename F>
+__host__ __device__ __forceinline__ void poly_for_each(const PolyRec &rec, const unsigned short *over, const PolyEdge *edges,
+                                                       int n, F &&f) {
+  unsigned w0 = rec.w[0], w1 = rec.w[1], w2 = rec.w[2], w3 = rec.w[3], w4 = rec.w[4], w5 = rec.w[5], w6 = rec.w[6], w7 = rec.w[7];
+  const unsigned cnt = w0 & 0xffffu;
+  if (cnt == 0u) return;
   const bool inl = cnt <= (unsigned)kPolyInline;
-  const unsigned off = (unsigned)((q0 >> 16) & 0xffffffffull);
-  for (unsigned k = 0; k < cnt; ++k) {
-    unsigned idx;
+  const unsigned off = (w0 >> 16) | (w1 << 16);
+  auto funnel = [](unsigned hi, unsigned lo) -> unsigned { return (lo >> 16) | (hi << 16); };   // v_alignbit_b32
+  auto next_index = [&](unsigned k) -> unsigned {
     if (inl) {   // next 16-bit word of the 256-bit record
-      q0 = (q0 >> 16) | (q1 << 48); q1 = (q1 >> 16) | (q2 << 48); q2 = (q2 >> 16) | (q3 << 48); q3 >>= 16;
-      idx = (unsigned)(q0 & 0xffffull);
-    } else {
-      idx = over[off + k];
+      w0 = funnel(w1, w0); w1 = funnel(w2, w1); w2 = funnel(w3, w2); w3 = funnel(w4, w3);
+      w4 = funnel(w5, w4); w5 = funnel(w6, w5); w6 = funnel(w7, w6); w7 >>= 16;
+      return w0 & 0xffffu;
     }
-    f((int)idx);
+    return over[off + k];
+  };
+  unsigned idx = next_index(0);
+  PolyEdge cur = edges[idx];
+  double nsx = 0.0, nsy = 0.0;
+  if constexpr (NEXT) { const PolyEdge &nx = edges[(idx + 1u == (unsigned)n) ? 0u : idx + 1u]; nsx = nx.sx; nsy = nx.sy; }
+  for (unsigned k = 0; k < cnt; ++k) {
+    const PolyEdge e = cur;
+    const double ex = nsx, ey = nsy;
+    const int i = (int)idx;
+    if (k + 1u < cnt) {
+      idx = next_index(k + 1u);
+      cur = edges[idx];
+      if constexpr (NEXT) { const PolyEdge &nx = edges[(idx + 1u == (unsigned)n) ? 0u : idx + 1u]; nsx = nx.sx; nsy = nx.sy; }
+    }
+    f(i, e, ex, ey);
   }
 }
 
@@ -126,9 +144,9 @@ template <bool CLOSEST>
 __host__ __device__ inline double poly_sdf(const PolyAccel &pa, const PolyEdge *edges, double x, double y, double *cminx,
                                            double *cminy) {
   double best = CLOSEST ? 1e9 : 1e300, mx = 0.0, my = 0.0;
-  auto visit = [&](int i) {
+  auto visit = [&](int, const PolyEdge &e, double, double) {
     double cx, cy;
-    const double d2 = poly_edge_d2(edges[i], x, y, cx, cy);
+    const double d2 = poly_edge_d2(e, x, y, cx, cy);
     if constexpr (CLOSEST) {
       const double dis = sqrt(d2);
       if (dis < best) { best = dis; mx = cx; my = cy; }
@@ -144,17 +162,14 @@ __host__ __device__ inline double poly_sdf(const PolyAccel &pa, const PolyEdge *
   const double fs = (y - pa.ymin) * pa.slab_inv_h;
   const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
   if (cell >= 0) {
-    poly_for_each(pa.cells[base + (unsigned)cell], pa.over, visit);
+    poly_for_each<false>(pa.cells[base + (unsigned)cell], pa.over, edges, pa.n, visit);
   } else {
-    for (int i = 0; i < pa.n; ++i) visit(i);
+    for (int i = 0; i < pa.n; ++i) visit(i, edges[i], 0.0, 0.0);
   }
   int rs = 0;
   if (ray) {
-    const int n = pa.n;
-    poly_for_each(pa.slabs[slab], pa.over, [&](int i) {
-      const PolyEdge &e = edges[i];
-      const PolyEdge &nx = edges[(i + 1 == n) ? 0 : i + 1];   // end of edge i = start of the next edge
-      if (poly_cross_ray(e.sx - x, e.sy - y, nx.sx - x, nx.sy - y)) rs++;
+    poly_for_each<true>(pa.slabs[slab], pa.over, edges, pa.n, [&](int, const PolyEdge &e, double ex, double ey) {
+      if (poly_cross_ray(e.sx - x, e.sy - y, ex - x, ey - y)) rs++;   // end of edge i = start of the next edge
     });
   }
   double dis_min;
@@ -230,15 +245,13 @@ inline PolyRec pack_list(const std::vector<unsigned short> &list, std::vector<un
     over.insert(over.end(), list.begin(), list.end());
   }
   PolyRec r;
-  for (int k = 0; k < 4; ++k)
-    r.q[k] = (unsigned long long)w[4 * k] | ((unsigned long long)w[4 * k + 1] << 16) | ((unsigned long long)w[4 * k + 2] << 32) |
-             ((unsigned long long)w[4 * k + 3] << 48);
+  for (int k = 0; k < 8; ++k) r.w[k] = (unsigned)w[2 * k] | ((unsigned)w[2 * k + 1] << 16);
   return r;
 }
 }  // namespace poly_detail
 
 // returns false when the outline cannot be handled (n out of range, non-finite vertex)
-inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng_fine = 128, int ng_coarse = 128,
+inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng_fine = 128, int ng_coarse = 256,
                              int nslab = 256) {
   using namespace poly_detail;
   if (n < 3 || n > kPolyMaxVerts) return false;

@@ -1,6 +1,6 @@
 // svsdf_shape_slice.hip -- one slice of the shape-templated kernels (compile with -DSVSDF_SLICE=k, k = 0 .. 3).
 //
-// Slice k instantiates k_solve / k_round / k_gsip / k_classify / k_rbound / k_subsw / k_shape_kernels for the shapes with
+// Slice k instantiates k_solve / k_round / k_classify / k_rbound / k_subsw / k_shape_kernels for the shapes with
 // id % 4 == k and exports the launchers svsdf_api.hip dispatches to (svsdf_launch.hpp).  Splitting the ~250 kernel
 // instantiations over four translation units lets the build run in parallel (one TU took 140 s).
 #include <hip/hip_runtime.h>
@@ -29,9 +29,13 @@ constexpr bool shape_enabled() {
 #endif
 }
 
+// k_solve / k_round also exist for the template value kPolygonLds (Polygon with its edges in LDS, svsdf_shapes.hpp)
+template <int S>
+constexpr bool kernel_shape_enabled() { return shape_enabled<S>() || S == kPolygonLds; }
+
 template <int S>
 bool solve_s(int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a) {
-  if constexpr (!shape_enabled<S>()) {
+  if constexpr (!kernel_shape_enabled<S>()) {
     return false;
   } else {
 #define SOLVE(GG)                                                                                                   \
@@ -54,7 +58,7 @@ bool solve_s(int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, c
 
 template <int S>
 bool round_s(int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a) {
-  if constexpr (!shape_enabled<S>()) {
+  if constexpr (!kernel_shape_enabled<S>()) {
     return false;
   } else {
 #define ROUND(LP, MODE)                                                                                             \
@@ -67,33 +71,6 @@ bool round_s(int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const 
       if (mode == 2) ROUND(32, 2); else if (mode == 1) ROUND(32, 1); else ROUND(32, 0);
     }
 #undef ROUND
-    return true;
-  }
-}
-
-template <int S>
-bool gsip_s(int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a) {
-  if constexpr (!shape_enabled<S>()) {
-    return false;
-  } else {
-#define GSIP(MODE)                                                                                                  \
-  do {                                                                                                              \
-    if (*a.blocks_per_cu <= 0) {                                                                                    \
-      int nb = 0;                                                                                                   \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gsip<S, MODE>, (int)block, lds) != hipSuccess || nb < 1) \
-        return false;                                                                                               \
-      *a.blocks_per_cu = nb;                                                                                        \
-    }                                                                                                               \
-    const unsigned g = std::min(grid, (unsigned)(*a.blocks_per_cu * a.n_cu));                                       \
-    const unsigned waves = g * (block / 64);                                                                        \
-    int nq = 1;                                                                                                     \
-    while (nq * 2 <= kMaxShards && (unsigned)(nq * 2) * 8u <= waves) nq *= 2;   /* >= 8 waves per shard */           \
-    hipLaunchKernelGGL((k_gsip<S, MODE>), dim3(g), dim3(block), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp, a.px, \
-                       a.py, a.gs, a.stride, a.sel_delta, a.sel_band, a.all_round, a.grace, nq, a.it0, a.res_sdf,     \
-                       a.res_t, a.res_gx, a.res_gy, a.ctl);                                                          \
-  } while (0)
-    if (mode == 2) GSIP(2); else if (mode == 1) GSIP(1); else GSIP(0);
-#undef GSIP
     return true;
   }
 }
@@ -133,7 +110,7 @@ bool subsw_s(dim3 grid, hipStream_t st, ShapeParams sp, const double *father, co
 template <int S>
 bool shape_kernels_s(unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu, int size_side,
                      double safemargin, const double *yaw, unsigned char *map) {
-  if constexpr (!shape_enabled<S>() || S == kPolygon) {   // Polygon has no (pos_rel, R_obj) overload (SHP:1477)
+  if constexpr (!shape_enabled<S>() || is_polygon<S>()) {   // Polygon has no (pos_rel, R_obj) overload (SHP:1477)
     return false;
   } else {
     hipLaunchKernelGGL((k_shape_kernels<S>), dim3(grid), dim3(kBlock), 0, st, sp, ks, count, resu, size_side, safemargin, yaw, map);
@@ -165,11 +142,6 @@ bool SLICE_FN(launch_k_round)(int shape, int lp, int mode, unsigned grid, size_t
 }
 bool SLICE_FN(launch_k_classify)(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a) {
 #define CALL(S) classify_s<S>(grid, lds, st, a)
-  SLICE_SWITCH(CALL)
-#undef CALL
-}
-bool SLICE_FN(launch_k_gsip)(int shape, int mode, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GsipLaunch &a) {
-#define CALL(S) gsip_s<S>(mode, grid, block, lds, st, a)
   SLICE_SWITCH(CALL)
 #undef CALL
 }

@@ -18,8 +18,22 @@ constexpr double kPI = 3.14159265358979323846;  // SHP:31
 enum ShapeId : int {
   kUnevenCapsule = 0, kCutDisk, kTrapezoid, kRhombus, kStar, kTunnel, kHorseshoe, kHeart,
   kOrientedVesica, kRoundedCross, kRoundedX, kBigX, kMoon, kPie, kPie2, kArc, kPolygon,
-  kShapeCount
+  kShapeCount,
+  // Kernel-template value only (never a svsdf_shape_id): Polygon whose edge array sits at the START of the block's dynamic
+  // LDS (k_solve / k_round of outlines of <= kPolyLdsMaxVerts vertices).  A compile-time LDS address lets the compiler
+  // use ds_read for the per-edge loads; a run-time choice between an LDS and a global pointer would make them flat loads.
+  kPolygonLds = kShapeCount,
+  kKernelShapeCount
 };
+constexpr int kPolyLdsMaxVerts = 1024;   // 40 KB of LDS
+
+// every kernel's `extern __shared__` array aliases the start of the block's dynamic LDS
+extern __shared__ double svsdf_dyn_lds[];
+template <int SHAPE>
+constexpr bool is_polygon() { return SHAPE == kPolygon || SHAPE == kPolygonLds; }
+// doubles at the start of the dynamic LDS that hold the Polygon's edges (kPolygonLds kernels), else 0
+template <int SHAPE>
+__device__ __forceinline__ size_t poly_lds_doubles(int nverts) { return SHAPE == kPolygonLds ? 5 * (size_t)nverts : 0; }
 
 // Host-prepared constants.  The reference evaluates cos/sin member initialisers with the host
 // libm at construction (SHP:855, 1237, 1278, 1320); we do the same on the host and pass them in.
@@ -31,8 +45,7 @@ struct ShapeParams {
   int identity;               // trans == 0 and Rotate == I (poly_params = 0): the transform is exact identity
   int nverts;                 // Polygon: outline vertices
   const PolyAccel *accel;     // Polygon: device pointer to the outline's candidate lists (svsdf_polygon.hpp)
-  const PolyEdge *edges;      // Polygon: the outline's edges (global memory; k_solve / k_round point it at their LDS copy)
-  int edges_lds;              // Polygon: 1 = the solve / round kernels stage the edges into LDS (host decision)
+  const PolyEdge *edges;      // Polygon: the outline's edges in global memory
 };
 
 // std::max / std::min.  Strict builds keep the compare+select form; the default uses v_max_f64 /
@@ -266,7 +279,9 @@ __device__ __forceinline__ double shape_core(const ShapeParams &sp, double px, d
 // getonlySDF(pos_rel): ((pos_rel - trans) * Rotate).head(2) then the shape formula.
 template <int SHAPE>
 __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, double y) {
-  if constexpr (SHAPE == kPolygon) {
+  if constexpr (SHAPE == kPolygonLds) {
+    return poly_sdf<false>(*sp.accel, reinterpret_cast<const PolyEdge *>(svsdf_dyn_lds), x, y, nullptr, nullptr);
+  } else if constexpr (SHAPE == kPolygon) {
     return poly_sdf<false>(*sp.accel, sp.edges, x, y, nullptr, nullptr);
   } else {
     double px = x, py = y;
@@ -284,7 +299,7 @@ __device__ __forceinline__ double shape_sdf(const ShapeParams &sp, double x, dou
 // for Polygon in the reference (SHP:1477 does not override the Matrix3d virtual).
 template <int SHAPE>
 __device__ __forceinline__ double shape_sdf_rot(const ShapeParams &sp, double x, double y, double c, double s) {
-  static_assert(SHAPE != kPolygon, "Polygon has no (pos_rel, R_obj) overload");
+  static_assert(!is_polygon<SHAPE>(), "Polygon has no (pos_rel, R_obj) overload");
   const double dx = x - sp.tx, dy = y - sp.ty;
   const double qx = dx * sp.r00 + dy * sp.r10;
   const double qy = dx * sp.r01 + dy * sp.r11;
@@ -297,7 +312,7 @@ __device__ __forceinline__ double shape_sdf_rot(const ShapeParams &sp, double x,
 template <int SHAPE>
 __device__ __forceinline__ void shape_grad(const ShapeParams &sp, double x, double y, double &gx,
                                            double &gy) {
-  if constexpr (SHAPE == kPolygon) {
+  if constexpr (is_polygon<SHAPE>()) {
     double cx, cy;
     const double sd = poly_sdf<true>(*sp.accel, sp.edges, x, y, &cx, &cy);
     double vx = x - cx, vy = y - cy;

@@ -312,8 +312,9 @@ typedef struct svsdf_stats {
   unsigned long long interior_points; /* points that entered the GSIP loop */
   unsigned long long solves;          /* argmin solves executed (main + selected GSIP samples) */
   unsigned long long gsip_samples;    /* GSIP circle samples emitted (the reference solves all of them) */
-  unsigned long long sdf_evals;       /* SDF-at-time evaluations executed on the device */
-  unsigned long long scan_evals;      /* of which layer-1 table evaluations */
+  unsigned long long sdf_evals;       /* SDF-at-time evaluations executed by the argmin kernel k_solve (layer-1 table
+                                         evaluations + full evaluations: polynomial, sincos, transform, shape) */
+  unsigned long long scan_evals;      /* of which layer-1 table evaluations (transform + shape only) */
   double device_ms;                   /* HIP-event time of the whole device pipeline (profiling on) */
   double solve_ms;                    /* HIP-event time during which >= 1 k_solve launch was executing (profiling on) */
   unsigned int solve_launches;        /* k_solve launches of the last evaluation */
@@ -331,6 +332,14 @@ typedef struct svsdf_stats {
                                          durations, or forced by SVSDF_FLAG_FAST_PIECE_TIME); 1, 2: the reference's chain */
   double solve_ms_sum;                /* plain sum of the k_solve launch durations (solve_ms merges the intervals of
                                          launches that ran concurrently on different streams) (profiling on) */
+  unsigned long long round_scan_evals; /* layer-1 table evaluations executed by k_round (seed scans of the GSIP samples
+                                          in the scanning bound modes; transform + shape only); NOT part of sdf_evals */
+  double round_ms;                    /* HIP-event time during which >= 1 k_round launch was executing (profiling on) */
+  double round_ms_sum;                /* plain sum of the k_round launch durations (profiling on) */
+  int batches;                        /* point batches (concurrent streams) the last evaluation ran as */
+  int plan_settled;                   /* 1 once bound mode, batch count and launch widths are fixed for this point set:
+                                         the first evaluations after svsdf_set_points decide them (<= 6 evaluations, all
+                                         with identical results); steady-state timing starts here */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 /* Shape bound used by the exact scan pruning and the exact cull: out2[0] = R with sdf_shape(q) >= |q| - R

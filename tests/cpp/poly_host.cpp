@@ -46,7 +46,7 @@ int polyhost_visits(const double *xy, int n, const double *pts, size_t P, int *l
     if (cell < 0) { cell = poly_cell(h.hdr.lv[1], pts[2 * i], pts[2 * i + 1]); lvl = 1; }
     if (cell < 0) { level_out[i] = 2; count_out[i] = n; continue; }
     level_out[i] = lvl;
-    count_out[i] = (int)(h.cells[h.hdr.lv[lvl].base + cell].q[0] & 0xffffull);
+    count_out[i] = (int)(h.cells[h.hdr.lv[lvl].base + cell].w[0] & 0xffffu);
   }
   return 0;
 }

@@ -37,7 +37,7 @@ def c2(built):
 
 
 def test_c2_full_size_solver_variants_bit_identical(c2):
-    """Pruned layer-1 scan == full scan, every lane-group width and the persistent GSIP kernel give the same
+    """Pruned layer-1 scan == full scan and every lane-group width / batch split give the same
     (sdf, t*, grad) for all 100k points (the restructurings are exact, not approximate)."""
     def run(env):
         def go():
@@ -56,11 +56,7 @@ def test_c2_full_size_solver_variants_bit_identical(c2):
                 dict(SVSDF_G=2, SVSDF_G_LATE=2, SVSDF_PRUNE=1, SVSDF_BATCHES=4),
                 dict(SVSDF_G=8, SVSDF_G_LATE=8, SVSDF_PRUNE=1, SVSDF_BATCHES=3),
                 dict(SVSDF_G=16, SVSDF_G_LATE=32, SVSDF_PRUNE=1, SVSDF_BATCHES=1),
-                dict(SVSDF_G=32, SVSDF_G_LATE=16, SVSDF_PRUNE=1, SVSDF_BATCHES=2),
-                # the GSIP loop as ONE persistent launch (k_gsip, device-side task queues), and as launches for three
-                # iterations + the persistent launch for the rest
-                dict(SVSDF_PERSISTENT=1, SVSDF_BATCHES=1),
-                dict(SVSDF_PERSISTENT=1, SVSDF_PERSISTENT_FROM=3, SVSDF_BATCHES=2)):
+                dict(SVSDF_G=32, SVSDF_G_LATE=16, SVSDF_PRUNE=1, SVSDF_BATCHES=2)):
         out, st = run(env)
         for a, b in zip(out, ref):
             assert np.array_equal(a, b), env
@@ -203,51 +199,3 @@ def test_gsip_bound_modes_are_invisible(built):
             assert st1["solves"] < 0.6 * st0["solves"]
 
 
-@pytest.mark.gpu
-def test_persistent_gsip_kernel_is_invisible(built):
-    """SVSDF_PERSISTENT=1 replaces the k_solve / k_round launch chain of the GSIP loop by one persistent launch per
-    batch (k_gsip: sharded task queues in device memory).  The per-point arithmetic is shared
-    (round_point, descend_from_seed), so cost, gradients and the per-point results must be bit-identical -- in every
-    bound mode, with several batches, on tiny shards (one wave, one queue shard) and without interior points."""
-    import svsdf_amd
-    from svsdf_amd import workload
-    cases = [("C2", 30000, {}), ("C3", 40000, dict(SVSDF_UB_FULL=1)), ("NS", 30000, dict(SVSDF_UB_FULL=2)),
-             ("C5", 8000, dict(SVSDF_UB_FULL=1)), ("C4", 30000, dict(SVSDF_BATCHES=3)), ("C1", 700, {}), ("C1", 3, {}),
-             # hybrid: the first three iterations as launches, the sparsely populated rest in the persistent launch
-             ("C3", 30000, dict(SVSDF_UB_FULL=1, SVSDF_PERSISTENT_FROM=3, SVSDF_BATCHES=2))]
-    for cfg, P, env in cases:
-        w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
-
-        def run():
-            ctx = _ctx(w)
-            ctx.set_points(w["points"])
-            outs = [ctx.eval_penalty(w["coeffs"], w["T"]) for _ in range(3)]   # the bound mode is decided after the first
-            st = ctx.stats()
-            q = ctx.query_points(w["coeffs"], w["T"])
-            return outs, st, q
-        o0, st0, q0 = _with_env(dict(env, SVSDF_PERSISTENT=0), run)
-        o1, st1, q1 = _with_env(dict(env, SVSDF_PERSISTENT=1), run)
-        for (c0, gT0, gC0), (c1, gT1, gC1) in zip(o0, o1):
-            assert c1 == c0, (cfg, P)
-            np.testing.assert_array_equal(gT1, gT0)
-            np.testing.assert_array_equal(gC1, gC0)
-        for a, b in zip(q0[:3], q1[:3]):
-            np.testing.assert_array_equal(a, b)
-        assert st1["gsip_bound_mode"] == st0["gsip_bound_mode"]
-        assert st1["interior_points"] == st0["interior_points"]
-        # one k_gsip launch per batch instead of one k_solve per GSIP iteration
-        if st0["interior_points"] > 0:
-            assert st1["solve_launches"] < st0["solve_launches"], (cfg, st0["solve_launches"], st1["solve_launches"])
-    # no interior point at all: the persistent launch has nothing to do
-    w = workload.make("C1", P=500, minco=svsdf_amd.minco_coeffs)
-    w["points"][:, 0] += 500.0
-
-    def far():
-        ctx = _ctx(w)
-        ctx.set_points(w["points"])
-        return ctx.eval_penalty(w["coeffs"], w["T"]), ctx.stats()
-    (ca, gTa, gCa), sa = _with_env(dict(SVSDF_PERSISTENT=0), far)
-    (cb, gTb, gCb), sb = _with_env(dict(SVSDF_PERSISTENT=1), far)
-    assert sa["interior_points"] == 0 and sb["interior_points"] == 0
-    assert ca == cb
-    np.testing.assert_array_equal(gCa, gCb)

@@ -190,6 +190,24 @@ def test_bench_c4_inprocess_two_stripes(built):
 
 
 @pytest.mark.gpu
+def test_bench_gpus_n_drives_n_devices_by_itself(built):
+    """A plain `python bench.py --gpus 2` (no torchrun, no --inprocess: the shape of the driver's N = 1 command with
+    another N) must drive two devices through the in-process multi-device context -- or refuse, never fall back to one
+    GPU and print n_gpus = 1."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        r = _bench(["--gpus", "2", "--points", "400000", "--steps", "2", "--warmup", "1", "--no-extras"])
+    else:
+        e = dict(os.environ)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=e,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode != 0 and b"GPU(s) visible" in out.stderr, out.stderr.decode()[-500:]
+        r = _bench(["--gpus", "2", "--devices", "0,0", "--points", "400000", "--steps", "2", "--warmup", "1", "--no-extras"])
+    assert r["n_gpus"] == 2 and r["config"]["points_per_gpu"] == 200000 and r["scaling"] == "strong"
+    assert r["config"]["shape"] == "sdHeart" and r["combine"]["ms_combine_inprocess"] is not None
+
+
+@pytest.mark.gpu
 def test_bench_c4_two_ranks_emulated(built):
     """bench.py --gpus 2 --config C4 as two torchrun ranks.  With two GPUs: the real RCCL path.  With one GPU both
     ranks share device 0 and the 5 KB all-reduce goes through gloo (RCCL refuses two ranks on one device)."""
