@@ -35,6 +35,7 @@ constexpr int kMaxSlots = 24;   // GSIP samples per round: 2, 6, 18, 21, 21, ...
 constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
 constexpr int kBlock = 256;
 constexpr int kMaxBatches = 8;
+constexpr int kMaxCand = 48;    // candidate chunks k_round keeps per (interior point, round); more: all chunks are walked
 // GSIP iterations: a round normally takes one iteration, plus one supplementary iteration when
 // the upper-bound selection (k_round) has to solve more samples of the same round.
 constexpr int kMaxIter = 24;
@@ -522,10 +523,13 @@ __device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wav
 // ---------------------------------------------------------------------------------------------
 // LITE (GSIP samples: no cull bound needed): square-root-free chunk tests -- first chunk = nearest centre, then
 // every chunk with |q - c|^2 <= (min + rb)^2 (1 + 1e-12), a superset of the exact test, so the seed is the same.
+// LITE scans may be restricted to a list of candidate chunks (clist[0 .. ncl), ascending; ncl < 0: all chunks): the list
+// k_round builds per (interior point, round) holds every chunk that can matter for ANY sample of the round's circle.
 template <int SHAPE, int G, bool LITE = false>
 __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *pose, const Chunk *chunks, int K,
                                             int nch, double px, double py, int prune, double cull_thresh,
-                                            double &best_d, int &best_k, bool &culled, unsigned &n_scan) {
+                                            double &best_d, int &best_k, bool &culled, unsigned &n_scan,
+                                            const unsigned short *clist = nullptr, int ncl = -1) {
   const int li = Grp<G>::li();
   best_d = 1e9;   // min_dis initial value (SWM:545)
   best_k = 0x7fffffff;
@@ -548,9 +552,12 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
     if (d_loc < best_d || (d_loc == best_d && k_loc < best_k)) { best_d = d_loc; best_k = k_loc; }
   };
   if constexpr (LITE) {
+    const int nl = (ncl < 0) ? nch : ncl;
+    auto chunk_at = [&](int j) -> int { return (ncl < 0) ? j : (int)clist[j]; };
     double d2_loc = 1e300;
     int c_loc = 0;
-    for (int c = li; c < nch; c += G) {
+    for (int j = li; j < nl; j += G) {
+      const int c = chunk_at(j);
       const Chunk ch = chunks[c];
       const double ex = px - ch.cx, ey = py - ch.cy;
       const double d2 = ex * ex + ey * ey;
@@ -559,21 +566,25 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
     Grp<G>::min_dk(d2_loc, c_loc);
     const int c0 = c_loc;
     eval_chunk(c0);
-    int c = 0;
-    while (c < nch) {
-      const int cc = c + li;
+    int j = 0;
+    while (j < nl) {
+      const int jj = j + li;
       bool need = false;
-      if (cc < nch && cc != c0) {
-        const Chunk ch = chunks[cc];
-        const double ex = px - ch.cx, ey = py - ch.cy;
-        const double t = best_d + ch.rb;
-        need = (t >= 0.0) && (ex * ex + ey * ey <= t * t * (1.0 + 1e-12));
+      int cc = 0;
+      if (jj < nl) {
+        cc = chunk_at(jj);
+        if (cc != c0) {
+          const Chunk ch = chunks[cc];
+          const double ex = px - ch.cx, ey = py - ch.cy;
+          const double t = best_d + ch.rb;
+          need = (t >= 0.0) && (ex * ex + ey * ey <= t * t * (1.0 + 1e-12));
+        }
       }
       const unsigned m = Grp<G>::ballot(need);
-      if (m == 0u) { c += G; continue; }
+      if (m == 0u) { j += G; continue; }
       const int first = __ffs(m) - 1;
-      eval_chunk(c + first);
-      c = c + first + 1;
+      eval_chunk(__shfl(cc, first, G));
+      j = j + first + 1;
     }
   } else if (!prune) {
     for (int c = 0; c < nch; ++c) eval_chunk(c);
@@ -966,7 +977,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
                                             const GsipState &gs, size_t stride, int start, int a, double delta,
                                             double band_delta, double *__restrict__ res_sdf, double *__restrict__ res_t,
                                             double *__restrict__ res_gx, double *__restrict__ res_gy, unsigned &n_scan,
-                                            RoundOut<(kMaxSlots + LP - 1) / LP> &out) {
+                                            RoundOut<(kMaxSlots + LP - 1) / LP> &out, unsigned short *clist, int clist_on) {
   constexpr bool FULL = MODE == 1;
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   const int l = (int)(threadIdx.x & (LP - 1));
@@ -1057,6 +1068,49 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       }
     }
     if (open) {
+      // ---- candidate chunks of this round: every sample y of the circle |y - p| = r has, for every table pose k of a
+      // chunk c,  |y - c| - rb_c <= sdf_k(y) <= |y - c| + rb_c  (rb_c = chunk radius + shape bound R: the shape has a
+      // point within R of the body origin), and |p - c| - |r| <= |y - c| <= |p - c| + |r|.  So every sample's table minimum is
+      // <= U = min_c (|p - c| + rb_c) + r, and a chunk with |p - c| - r - rb_c > U holds no table pose that can be, or tie
+      // with, ANY sample's minimum -- nor can it be the chunk with the centre nearest to a sample (|p - c| - r > min |p - c'|
+      // + r follows).  The scans and the cheap bound below walk this list (ascending, in LDS) instead of all chunks:
+      // same seeds, same bounds; most of a long path's chunks drop out once the circle is small (rounds >= 3).
+      int ncl = -1;
+      {
+        double u = 1e300;
+        for (int c = l; c < nch; c += LP) {
+          const Chunk ch = chunks[c];
+          u = dmin(u, norm2(cx - ch.cx, cy - ch.cy) + ch.rb);
+        }
+        u = dmin(u, Grp<LP>::template xchg<0>(u));
+        u = dmin(u, Grp<LP>::template xchg<1>(u));
+        u = dmin(u, Grp<LP>::template xchg<2>(u));
+        if constexpr (LP == 32) {
+          u = dmin(u, Grp<LP>::template xchg<3>(u));
+          u = dmin(u, Grp<LP>::template xchg<4>(u));
+        }
+        // (the reference's radius update r <- r - max_g can turn r NEGATIVE when a sample's local argmin search ended in a
+        // far basin, max_g > r: the circle then has radius |r|)
+        const double ra = fabs(r);
+        const double thr = (u + ra) * (1.0 + 1e-12) + 1e-9;
+        int cnt = 0;
+        for (int cb = 0; cb < nch; cb += LP) {
+          const int c = cb + l;
+          bool keep = false;
+          if (c < nch) {
+            const Chunk ch = chunks[c];
+            keep = (norm2(cx - ch.cx, cy - ch.cy) - ra) - ch.rb <= thr;
+          }
+          const unsigned mk = ballot_g(keep);
+          const int pos = cnt + __popc(mk & lt_mask);
+          if (keep && pos < kMaxCand) clist[pos] = (unsigned short)c;
+          cnt += __popc(mk);
+        }
+        if (cnt <= kMaxCand && nch <= 65535 && clist_on) ncl = cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the point's lanes (one wave) read each other's entries
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
       // ---- open a round: lane l takes samples l, l + LP, ...
       double theta = theta0;
       for (int q = 0; q < l; ++q) theta += theta_res;
@@ -1081,7 +1135,10 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
             double d2min = 1e300;
             int c0 = 0;
-            for (int c = 0; c < nch; ++c) {
+            const int ncl_c = (clist_on & 2) ? ncl : -1;
+            const int nl_c = (ncl_c < 0) ? nch : ncl_c;
+            for (int jc = 0; jc < nl_c; ++jc) {
+              const int c = (ncl_c < 0) ? jc : (int)clist[jc];
               const Chunk ch = chunks[c];
               const double ex = qx - ch.cx, ey = qy - ch.cy;
               const double d2 = ex * ex + ey * ey;
@@ -1120,7 +1177,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           int bk = 0;
           if (sidx < n_emit) {
             bool cu;
-            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
+            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1);
           }
           // hand the result to the lane that owns the sample: sub-group (j % SG) scanned sample j in pass j / SG
           const double rb = __shfl(bd, (l % SG) * 8, LP);
@@ -1196,7 +1253,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             int bk = 0;
             if (found) {
               bool cu;
-              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan);
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1);
             }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
@@ -1261,12 +1318,13 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
         const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta, double band_delta,
         double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx,
-        double *__restrict__ res_gy, BatchCtl *__restrict__ ctl) {
+        double *__restrict__ res_gy, BatchCtl *__restrict__ ctl, int clist_on) {
   static_assert(LP == 8 || LP == 32, "lanes per point");
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   extern __shared__ double round_lds[];
   __shared__ int s_cnt[3][kRoundBlock / LP];   // per point slot: solves, next-list entries, samples
   __shared__ int s_base[2][kRoundBlock / LP];  // per point slot: solve-list / next-list positions
+  __shared__ unsigned short s_clist[(kRoundBlock / LP) * kMaxCand];   // per point slot: candidate chunks of its round
   const int n_act = ctl->n_active[it];
   const int ppb = blockDim.x / LP;  // points per block
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
@@ -1309,7 +1367,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     if (active) {
       a = cur[e];
       round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, delta, band_delta, res_sdf,
-                                   res_t, res_gx, res_gy, n_scan, ro);
+                                   res_t, res_gx, res_gy, n_scan, ro, s_clist + (size_t)hw * kMaxCand, clist_on);
     }
     ia = (size_t)start + a;
     push_next = ro.push_next;

@@ -20,6 +20,7 @@ struct SolveLaunch {   // arguments of k_solve<SHAPE, G, 1>
 struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
   const TrajDev *traj; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py; GsipState gs;
   size_t stride; int it; double delta, band_delta; double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl;
+  int clist_on;   // 1: scans / cheap bounds walk the per-point candidate-chunk list (0: all chunks; same results)
 };
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
   const TrajDev *traj; ShapeParams sp; const double *px, *py, *sdf, *t; double *res_sdf, *res_t, *res_gx, *res_gy;

@@ -64,7 +64,7 @@ bool round_s(int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const 
 #define ROUND(LP, MODE)                                                                                             \
   hipLaunchKernelGGL((k_round<S, LP, MODE>), dim3(grid), dim3(kRoundBlock), lds, st, a.traj, a.pose, a.chunks, a.sp, \
                      a.px, a.py, a.gs, a.stride, a.it, a.delta, a.band_delta, a.res_sdf, a.res_t, a.res_gx,          \
-                     a.res_gy, a.ctl)
+                     a.res_gy, a.ctl, a.clist_on)
     if (lp == 8) {
       if (mode == 2) ROUND(8, 2); else if (mode == 1) ROUND(8, 1); else ROUND(8, 0);
     } else {

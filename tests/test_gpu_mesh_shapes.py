@@ -82,6 +82,28 @@ def test_c5_map_distribution_and_far_points(built):
     assert np.array_equal(ts, ots) and np.array_equal(sdf, osdf) and np.array_equal(g, og)
 
 
+def test_c5_negative_gsip_radius_case(built, monkeypatch):
+    """C5 at 20 k points holds an interior point whose GSIP radius update r <- r - max_g (sw_manager.hpp:1003-1006) turns
+    NEGATIVE (a circle sample's local argmin search ends in a far basin, max_g > r): the reference then samples the circle
+    of radius |r| and reports a positive "SVSDF" for an interior point.  k_round's candidate-chunk lists once assumed
+    r >= 0 there (round 3): every point, in the full-scan bound mode, must match the oracle bit for bit."""
+    monkeypatch.setenv("SVSDF_UB_FULL", "1")
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make("C5", P=20000, minco=svsdf_amd.minco_coeffs)
+    kw = dict(safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"], polygon=w["polygon"],
+              head_state=w["head_state"], tail_state=w["tail_state"])
+    ctx = svsdf_amd.SvsdfContext(shape="Polygon", device=0, **kw)
+    ctx.set_points(w["points"])
+    o = orc.Oracle("Polygon", **kw)
+    o.set_traj(w["coeffs"], w["T"])
+    o.set_trig_mode(1)
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    osdf, ots, og = o.query(w["points"], nthreads=NT)
+    assert np.array_equal(ts, ots) and np.array_equal(sdf, osdf) and np.array_equal(g, og)
+    assert ctx.stats()["gsip_bound_mode"] == 1
+
+
 def test_polygon_vertex_limit(built):
     import svsdf_amd
     ang = np.linspace(0, 2 * np.pi, 4096, endpoint=False)
