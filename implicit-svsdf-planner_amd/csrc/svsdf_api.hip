@@ -339,7 +339,7 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per
   // point; later rounds have 18-21 samples: 32 lanes per point (either handles any count)
   const int lp = (it < ctx->round_lp8_iters) ? 8 : 32;
-  const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, 1024);
+  const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, (long long)(256 * 16 * 64) / kRoundBlock);
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta,
                       band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b, ctx->round_list};
   size_t e0 = 0, e1 = 0;

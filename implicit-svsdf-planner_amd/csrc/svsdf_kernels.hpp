@@ -1306,8 +1306,14 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 
 // LP lanes per point (8 or 32): the early rounds have 2 and 6 samples, the later ones 18-21; a
 // point with more samples than lanes is handled in ceil(n / LP) passes.
+// Block size of k_round.  Every block iteration ends in barriers (block-aggregated list atomics), and a block waits for its
+// slowest point (a round with 21 sample scans next to one that just closes).  With 1024 threads a block IS the CU's whole
+// complement of waves (116 VGPRs -> 4 waves per SIMD), so the CU idles at every barrier: counters showed the waves
+// waiting 55 ... 67 % of their cycles.  256 threads leave four independent blocks per CU: C3 8.6 -> 7.7 ms, NS 11.0 ->
+// 10.1 ms (round 3; 128 / 64 threads lose again to 4 - 8 x the list atomics).  Round 2 had measured smaller blocks at
+// -3.6 % only -- before the concurrent batches, whose tails the free blocks now fill.
 #ifndef SVSDF_ROUND_BLOCK
-#define SVSDF_ROUND_BLOCK 1024
+#define SVSDF_ROUND_BLOCK 256
 #endif
 constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
 // MODE: 0 cheap bound (nearest chunk), 1 full (every new sample scanned), 2 lazy (cheap bound for all, the sample's own
