@@ -864,6 +864,12 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 #define SVSDF_LAZY_REPS 2   // scan passes of the lazy bound mode: the band, then its extension (a third changes nothing)
 #endif
 enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
+// Sample slot of (interior point ia, sample j).  POINT-major: the <= 24 samples of a point are consecutive, so the lanes of
+// a point (lane j <-> sample j) read / write one or two cache lines per array instead of 21 lines 8 MB apart (the slot-major
+// layout of rounds 1-2: k_round's sample arrays were 0.4 GB of the 0.87 GB an evaluation moved).  `stride` (points in the
+// shard) is kept in the signatures for the diagnostics that still think slot-major.
+__host__ __device__ __forceinline__ size_t sample_slot(size_t /*stride*/, size_t ia, int j) { return ia * (size_t)kMaxSlots + (size_t)j; }
+
 struct GsipState {
   int *pt;          // index of the (sorted) main point
   double *r;        // current circle radius
@@ -874,7 +880,7 @@ struct GsipState {
   int *phase;       // kPhaseNew: a round has to be opened; kPhaseEval / kPhaseSupp: samples are out
   int *list[2];     // ping-pong compacted lists of still-active interior indices
   int *solve;       // sample slots to solve in the current iteration (capacity kMaxSlots per point)
-  // sample slots [j * stride + batch start + a]
+  // sample slots: sample_slot(stride, batch start + a, j)
   double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
   int *sq_k;        // layer-1 seed index of the sample (full-scan mode: sq_ub is then the seed value)
 };
@@ -1009,7 +1015,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        g_mine[ps] = (j < n) ? gs.sq_sdf[(size_t)j * stride + ia] : kUnsolved;
+        g_mine[ps] = (j < n) ? gs.sq_sdf[sample_slot(stride, ia, j)] : kUnsolved;
         if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
       }
       {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
@@ -1024,7 +1030,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       }
       double max_g = -100000, real_t = res_t[i], star_th = 0.0;
       if (g > max_g) {
-        const size_t sb = (size_t)idx * stride + ia;
+        const size_t sb = sample_slot(stride, ia, idx);
         max_g = g; real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
       }
       // unsolved samples that could still reach max_g -> supplementary solves
@@ -1032,7 +1038,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gs.sq_ub[(size_t)j * stride + ia] >= max_g;
+        list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gs.sq_ub[sample_slot(stride, ia, j)] >= max_g;
         mlist[ps] = ballot_g(list_me[ps]);
         any = any || (mlist[ps] != 0u);
       }
@@ -1127,7 +1133,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         kk[ps] = 0;
         sqx_l[ps] = 0.0; sqy_l[ps] = 0.0;
         if (valid[ps]) {
-          const size_t s = (size_t)j * stride + ia;
+          const size_t s = sample_slot(stride, ia, j);
           const double qx = cx + 1.0 * r * cos(theta);
           const double qy = cy + 1.0 * r * sin(theta);
           sqx_l[ps] = qx; sqy_l[ps] = qy;
@@ -1189,7 +1195,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
           if (valid[ps]) {
-            const size_t s = (size_t)(l + LP * ps) * stride + ia;
+            const size_t s = sample_slot(stride, ia, l + LP * ps);
             gs.sq_ub[s] = ub[ps];
             gs.sq_k[s] = kk[ps];
           }
@@ -1279,7 +1285,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
           if (valid[ps]) {
-            const size_t s = (size_t)(l + LP * ps) * stride + ia;
+            const size_t s = sample_slot(stride, ia, l + LP * ps);
             gs.sq_ub[s] = ub[ps];
             gs.sq_k[s] = kk[ps];
             if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
@@ -1404,7 +1410,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
       int pos = s_base[0][hw];
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
-        if (list_me[ps]) solve[pos + __popc(mlist[ps] & lt_mask)] = (int)((size_t)(l + LP * ps) * stride + ia);
+        if (list_me[ps]) solve[pos + __popc(mlist[ps] & lt_mask)] = (int)sample_slot(stride, ia, l + LP * ps);
         pos += __popc(mlist[ps]);
       }
     }

@@ -4,6 +4,9 @@
 // 3P point doubles.  Output: cost, cost_pos, cost_other, cost_total, then g[0..n); with --optimize also
 // ret, iterations, final cost, cost_total and the optimised x[0..n).  `--devices 0,1,...` makes the ONE TrajOptimizerHip
 // of this process drive several GPUs (svsdf_config::n_devices; a device may repeat: several stripes on one GPU).
+// `--reconfig`: after the first evaluation the public member safety_hor is edited (x 1.5) like the reference's members
+// can be, and the callback is evaluated again (the mirror rebuilds its context): cost and cost_pos of the second call
+// follow.  An inputdata whose stem the shape registry does not know is read as an .obj mesh (z = 0 outline -> Polygon).
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -51,6 +54,11 @@ int main(int argc, char **argv) {
   const double f = eval(&opt, x.data(), g.data(), n);
   std::printf("%.17g %.17g %.17g %.17g\n", f, opt.cost_pos, opt.cost_other, opt.cost_total);
   for (int i = 0; i < n; ++i) std::printf("%.17g\n", g[i]);
+  if (argc > 1 && std::string(argv[1]) == "--reconfig") {
+    opt.safety_hor = 1.5 * sh;
+    const double f2 = eval(&opt, x.data(), g.data(), n);
+    std::printf("%.17g %.17g\n", f2, opt.cost_pos);
+  }
   if (argc > 1 && std::string(argv[1]) == "--optimize") {
     // optimize_traj_lmbm(initS, finalS, opt_x, N, traj) call shape of plan_manager.cpp:176
     svsdf_lbfgs_params prm;

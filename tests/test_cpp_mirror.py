@@ -86,6 +86,67 @@ def test_cpp_mirror_drives_several_devices_from_one_process(built):
     np.testing.assert_allclose(b[4:], a[4:], rtol=0, atol=1e-12 * np.abs(a[4:]).max())
 
 
+@pytest.mark.gpu
+def test_cpp_mirror_follows_edited_members_and_reads_meshes(built, tmp_path):
+    """(a) ADVICE r2: the mirror keeps its context across optimisations, so an edit of a Config-derived public member
+    (safety_hor here) between two callbacks must rebuild it -- the second evaluation equals a fresh context's.
+    (b) BASELINE config 5 through the C++ host: an inputdata the shape registry does not know is read as an .obj mesh and
+    planned with the Polygon SDF of its z = 0 outline -- equal to the ctypes path fed with svsdf_mesh_outline's result."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    exe = _build()
+    w = workload.make("C1", P=700, minco=svsdf_amd.minco_coeffs)
+    N = len(w["T"])
+    x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+    col = lambda m: " ".join(repr(float(v)) for v in np.asfortranarray(m).ravel(order="F"))
+
+    def run(inputdata, mode):
+        inp = f"{inputdata} {w['safety_hor']!r} {w['weight_p']!r} {w['rho']!r} {N} {len(w['points'])}\n"
+        inp += col(w["head_state"]) + "\n" + col(w["tail_state"]) + "\n"
+        inp += " ".join(repr(float(v)) for v in x) + "\n"
+        inp += " ".join(repr(float(v)) for v in w["points"].ravel()) + "\n"
+        out = subprocess.run([exe] + mode, input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split()
+        return [float(v) for v in out]
+    kw = dict(weight_p=w["weight_p"], rho=w["rho"], head_state=w["head_state"], tail_state=w["tail_state"], device=0)
+    # (a)
+    vals = run("shapes/star.obj", ["--reconfig"])
+    n = len(x)
+    c1 = svsdf_amd.SvsdfContext(shape="star", safety_hor=w["safety_hor"], **kw)
+    c1.set_points(w["points"])
+    c2 = svsdf_amd.SvsdfContext(shape="star", safety_hor=1.5 * w["safety_hor"], **kw)
+    c2.set_points(w["points"])
+    f1, _ = c1.lmbm_evaluate(x)
+    f2, _ = c2.lmbm_evaluate(x)
+    assert vals[0] == f1 and vals[4 + n] == f2 and f2 > f1 and vals[5 + n] == c2.last_costs()[0]
+    # (b) the reference's star mesh under a name the registry does not know
+    V, F = workload.reference_mesh("star")
+    obj = tmp_path / "robot_body.obj"
+    with open(obj, "w") as f:
+        for v in V:
+            f.write("v %.6f %.6f %.6f\n" % tuple(v))
+        for t in F:
+            f.write("f %d %d %d\n" % tuple(t + 1))
+    vals = run(str(obj), [])
+    poly, loops = svsdf_amd.mesh_outline_obj(obj)
+    assert loops == 1 and len(poly) == 77
+    c3 = svsdf_amd.SvsdfContext(shape="Polygon", polygon=poly, safety_hor=w["safety_hor"], **kw)
+    c3.set_points(w["points"])
+    f3, g3 = c3.lmbm_evaluate(x)
+    assert vals[0] == f3
+    np.testing.assert_array_equal(vals[4:4 + n], g3)
+    # and the Python mirror resolves the same file the same way
+    opt = svsdf_amd.TrajOptimizer()
+    opt.setParam(dict(rho=w["rho"], weight_p=w["weight_p"], safety_hor=w["safety_hor"], inputdata=str(obj), device=0))
+    opt.setConditions(w["head_state"], w["tail_state"], N)
+    opt.setPoints(w["points"])
+    f4, g4 = opt.costFunctionLmbmParallel(x)
+    assert f4 == f3 and np.array_equal(g4, g3)
+    # a one-element device list means that device (ADVICE r2)
+    c5 = svsdf_amd.SvsdfContext(shape="star", safety_hor=w["safety_hor"], devices=[0], **{k: v for k, v in kw.items() if k != "device"})
+    c5.set_points(w["points"])
+    assert c5.lmbm_evaluate(x)[0] == f1 and c5.stats()["n_devices"] == 1
+
+
 # ---- the lbfgs::lbfgs_evaluate_t adapter (lbfgs.hpp:213-216; north_star "preserves the lbfgs_optimize callback
 # signature").  The image has no Eigen: the mirror is compiled against tests/cpp/mini_eigen.hpp (data()/size() only).
 ADAPTER = os.path.join(ROOT, "tests", "cpp", "lbfgs_adapter_driver")

@@ -167,7 +167,7 @@ def test_sharded_contexts_sum_to_whole(built):
     np.testing.assert_allclose(acc_T, full[1], rtol=1e-9, atol=1e-9)
 
 
-def _budget_points(evals_per_point, seconds=4.0):
+def _budget_points(evals_per_point, seconds=8.0):
     """Points the oracle finishes in ~`seconds` on this host (~1.2e6 SDF evaluations/s per core, measured)."""
     return int(seconds * 1.2e6 * NT / evals_per_point)
 

@@ -165,6 +165,17 @@ def test_rccl_combine(built):
     np.testing.assert_allclose(gTg, gT1, rtol=0, atol=1e-12 * np.abs(gT1).max())
     with pytest.raises(svsdf_amd.SvsdfError, match="distinct"):
         _ctx(w, devices=[0, 0], combine=svsdf_amd.COMBINE_RCCL)
+    # a stripe that fails (here: every stripe, on a non-positive duration) still JOINS the collective with a poisoned
+    # partial instead of returning early and leaving the other device threads blocked in the all-reduce: the
+    # call comes back with an error, and the context keeps working afterwards
+    Tbad = np.array(w["T"], dtype=float)
+    Tbad[3] = -1.0
+    with pytest.raises(svsdf_amd.SvsdfError):
+        grp.eval_penalty(w["coeffs"], Tbad)
+    cg2, _, gCg2 = grp.eval_penalty(w["coeffs"], w["T"])
+    assert cg2 == cg and np.array_equal(gCg2, gCg)
+    st = grp.stats()
+    assert st["plan_settled"] in (0, 1) and st["batches"] >= 1 and st["round_scan_evals"] >= 0
 
 
 def _bench(args, env=None, launcher=None):
