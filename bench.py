@@ -130,8 +130,10 @@ class Runner:
         self.set_points_ms = 1e3 * (time.perf_counter() - t0)
         self.x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
         self.zT, self.zC = np.zeros(N), np.zeros((6 * N, 3))
+        self.n_eval = 0      # device evaluations issued by this runner (tools/profile_round.sh divides counters by it)
 
     def step(self):
+        self.n_eval += 1
         return self.opt.addSaftyPenaOnSweptVolumeParallelTrueSDF(self.w["T"], self.w["coeffs"], 0.0, self.zT, self.zC)
 
     def fence(self):
@@ -219,6 +221,7 @@ class Runner:
         T = svsdf_amd.forward_T(x[:N])
         coeffs = svsdf_amd.minco_coeffs(self.w["head_state"], self.w["tail_state"], x[N:].reshape(-1, 3), T)
         f = lambda: self.opt.addSaftyPenaOnSweptVolumeParallelTrueSDF(T, coeffs, 0.0, self.zT, self.zC)
+        self.n_eval += 3 + steps
         for _ in range(3):
             f()
         self.fence()
@@ -242,6 +245,7 @@ class Runner:
         callbacks of an optimisation: the launch plan learned from the previous call no longer matches exactly."""
         rng = np.random.default_rng(seed)
         xs = [self.x * (1.0 + perturb * rng.standard_normal(len(self.x))) if perturb else self.x for _ in range(steps)]
+        self.n_eval += 1 + steps
         self.opt.costFunctionLmbmParallel(self.x)
         self.fence()
         t0 = time.perf_counter()
@@ -460,6 +464,7 @@ def main():
     }
     if generic is not None:
         res["generic_durations"] = generic
+    res["evaluations_in_this_run"] = r.n_eval   # of the headline workload (settle + warm-up + timed + profiled + callbacks)
     if multi or devices is not None or ar_ms is not None:
         res["combine"] = {"ms_allreduce": ar_ms, "ms_combine_inprocess": combine_ms if a.inprocess else None,
                           "mode": ["host", "host", "rccl"][last["combine"]] if a.inprocess else "torch.distributed",

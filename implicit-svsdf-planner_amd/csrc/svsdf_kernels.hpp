@@ -864,11 +864,15 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 #define SVSDF_LAZY_REPS 2   // scan passes of the lazy bound mode: the band, then its extension (a third changes nothing)
 #endif
 enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
-// Sample slot of (interior point ia, sample j).  POINT-major: the <= 24 samples of a point are consecutive, so the lanes of
-// a point (lane j <-> sample j) read / write one or two cache lines per array instead of 21 lines 8 MB apart (the slot-major
-// layout of rounds 1-2: k_round's sample arrays were 0.4 GB of the 0.87 GB an evaluation moved).  `stride` (points in the
-// shard) is kept in the signatures for the diagnostics that still think slot-major.
+// Sample slot of (interior point ia, sample j): slot-major [j * stride + ia] (stride = points in the shard).  A point-major
+// layout [ia * 24 + j] -- the samples of a point in one or two cache lines for k_round's lanes -- was measured in round 3
+// (tools/traffic_ab.sh, -DSVSDF_POINT_MAJOR): same evaluation time, but MORE HBM traffic (k_solve's reads of the selected
+// samples 69 -> 183 MB per C3 evaluation: a solve list walks neighbouring points at similar j), so slot-major stays.
+#ifdef SVSDF_POINT_MAJOR
 __host__ __device__ __forceinline__ size_t sample_slot(size_t /*stride*/, size_t ia, int j) { return ia * (size_t)kMaxSlots + (size_t)j; }
+#else
+__host__ __device__ __forceinline__ size_t sample_slot(size_t stride, size_t ia, int j) { return (size_t)j * stride + ia; }
+#endif
 
 struct GsipState {
   int *pt;          // index of the (sorted) main point
@@ -880,7 +884,7 @@ struct GsipState {
   int *phase;       // kPhaseNew: a round has to be opened; kPhaseEval / kPhaseSupp: samples are out
   int *list[2];     // ping-pong compacted lists of still-active interior indices
   int *solve;       // sample slots to solve in the current iteration (capacity kMaxSlots per point)
-  // sample slots: sample_slot(stride, batch start + a, j)
+  // sample slots: sample_slot(stride, batch start + a, j) = [j * stride + batch start + a]
   double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
   int *sq_k;        // layer-1 seed index of the sample (full-scan mode: sq_ub is then the seed value)
 };

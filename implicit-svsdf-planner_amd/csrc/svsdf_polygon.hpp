@@ -161,17 +161,21 @@ __host__ __device__ inline double poly_sdf(const PolyAccel &pa, const PolyEdge *
   const bool ray = y >= pa.ymin - pa.tol && y <= pa.ymax + pa.tol && x <= pa.xmax + pa.tol;
   const double fs = (y - pa.ymin) * pa.slab_inv_h;
   const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
+  // both candidate records are fetched before either list is walked (two independent loads in flight instead of the
+  // second one waiting behind the distance loop)
+  PolyRec rec_d, rec_p;
+  for (int k = 0; k < 8; ++k) { rec_d.w[k] = 0u; rec_p.w[k] = 0u; }
+  if (cell >= 0) rec_d = pa.cells[base + (unsigned)cell];
+  if (ray) rec_p = pa.slabs[slab];
   if (cell >= 0) {
-    poly_for_each<false>(pa.cells[base + (unsigned)cell], pa.over, edges, pa.n, visit);
+    poly_for_each<false>(rec_d, pa.over, edges, pa.n, visit);
   } else {
     for (int i = 0; i < pa.n; ++i) visit(i, edges[i], 0.0, 0.0);
   }
   int rs = 0;
-  if (ray) {
-    poly_for_each<true>(pa.slabs[slab], pa.over, edges, pa.n, [&](int, const PolyEdge &e, double ex, double ey) {
-      if (poly_cross_ray(e.sx - x, e.sy - y, ex - x, ey - y)) rs++;   // end of edge i = start of the next edge
-    });
-  }
+  poly_for_each<true>(rec_p, pa.over, edges, pa.n, [&](int, const PolyEdge &e, double ex, double ey) {
+    if (poly_cross_ray(e.sx - x, e.sy - y, ex - x, ey - y)) rs++;   // end of edge i = start of the next edge
+  });
   double dis_min;
   if constexpr (CLOSEST) {
     dis_min = best;

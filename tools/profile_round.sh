@@ -19,8 +19,10 @@ KS=$(find $OUT/${TAG}_kt -name '*kernel_stats.csv' | head -1); cp $KS $OUT/${TAG
 F=$(find $OUT/${TAG}_pmc_f -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/${TAG}_pmc_w -name '*counter_collection.csv' | head -1)
 S=$(find $OUT/${TAG}_pmc_s -name '*counter_collection.csv' | head -1)
-# evaluations per profiled run: 2 settle + 1 warm-up + 5 timed + 5 event-profiled + 7 serialised-profiled + 12 full-callback = 32
-python $ROOT/tools/pmc_summary.py $F $W $S ${3:-32} "rocprofv3 PMC summary, bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-extras, 1x MI355X, $TAG" > $OUT/${TAG}_bench_${CFG}_pmc_summary.txt
+# evaluations per profiled run: bench.py counts them itself (settle + warm-up + timed + event-profiled + serialised-profiled +
+# generic-durations + full-callback passes)
+NEV=$(python -c "import json,sys; print(json.load(open('$OUT/${TAG}_bench_${CFG}_short.json'))['evaluations_in_this_run'])")
+python $ROOT/tools/pmc_summary.py $F $W $S ${3:-$NEV} "rocprofv3 PMC summary, bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-extras, 1x MI355X, $TAG" > $OUT/${TAG}_bench_${CFG}_pmc_summary.txt
 KT=$(find $OUT/${TAG}_kt -name '*kernel_trace.csv' | head -1)
 python $ROOT/tools/timeline.py $KT 6 > $OUT/${TAG}_bench_${CFG}_timeline.txt 2>&1
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_s
