@@ -772,8 +772,10 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
 //    per-trial re-evaluation returns the same number.
 // LDS: [Polygon edges 5 nverts (kPolygonLds only) | pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
 // ---------------------------------------------------------------------------------------------
+// (Polygon: 172 VGPRs would mean 2 waves per SIMD for a kernel that waits on its candidate-record loads; asking for 3
+// blocks of 4 waves per CU caps it at 168 with two spilled registers: C5 43.3 -> 38.7 ms)
 template <int SHAPE, int G, int U>
-__global__ void __launch_bounds__(kBlock, SVSDF_SOLVE_WAVES)
+__global__ void __launch_bounds__(kBlock, is_polygon<SHAPE>() ? 3 : SVSDF_SOLVE_WAVES)
 k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
         double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh) {
