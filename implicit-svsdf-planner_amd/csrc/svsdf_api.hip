@@ -746,7 +746,11 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
     if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
     ctx->ub_tune = 1;
-    if (ctx->ub_full && ctx->want_batches == 0 && large) {
+  }
+  // the batch count is measured once per point set, also when the bound mode was pinned by the environment
+  if (rc == SVSDF_OK && (deciding || (ctx->ub_env && ctx->ub_tune == 0))) {
+    ctx->ub_tune = 1;
+    if (ctx->ub_full && ctx->want_batches == 0 && ctx->P >= 400000) {
       ctx->bt_state = 1;
       ctx->bt_cand[0] = 1;
       ctx->bt_cand[1] = ctx->ub_lazy ? 2 : 4;
@@ -1401,7 +1405,12 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     }
     // candidate lists of the outline (svsdf_polygon.hpp), then one upload: the header's pointers are device addresses
     PolyAccelHost pa;
-    if (!build_poly_accel(v.data(), (int)(v.size() / 2), pa)) return bail("svsdf_create: polygon outline rejected (non-finite vertex?)");
+    int ngf = 128, ngc = 256;   // grid cells per side, fine / coarse (env SVSDF_POLY_GRID="f,c": experiments)
+    if (const char *e = std::getenv("SVSDF_POLY_GRID")) {
+      int a = 0, b = 0;
+      if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 8 && a <= 1024 && b >= 8 && b <= 1024) { ngf = a; ngc = b; }
+    }
+    if (!build_poly_accel(v.data(), (int)(v.size() / 2), pa, ngf, ngc)) return bail("svsdf_create: polygon outline rejected (non-finite vertex?)");
     auto align = [](size_t o) { return (o + 63) & ~(size_t)63; };
     const size_t o_edges = align(sizeof(PolyAccel));
     const size_t o_cell = align(o_edges + pa.edges.size() * sizeof(PolyEdge));
