@@ -1,5 +1,6 @@
 """One-off parity run at BASELINE.json's FULL sizes (GPU box, 256 host cores; minutes of CPU): HIP path vs the oracle
-of record on every point of the workload.  usage: python tools/full_size_parity.py NS C3 C4 C5"""
+of record on every point of the workload.  usage: python tools/full_size_parity.py NS C3 C4 C5:100000
+(CFG:P limits a workload to its first P points: the 77-vertex Polygon of C5 costs the oracle ~1.2 ms per point and core)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "implicit-svsdf-planner_amd")]
@@ -8,8 +9,9 @@ from svsdf_amd import workload
 from oracle import orc
 NT = os.cpu_count() or 1
 rel = lambda a, b: float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300))
-for cfg in sys.argv[1:]:
-    w = workload.make(cfg, minco=svsdf_amd.minco_coeffs)
+for arg in sys.argv[1:]:
+    cfg, _, lim = arg.partition(":")
+    w = workload.make(cfg, P=int(lim) if lim else None, minco=svsdf_amd.minco_coeffs)
     P = len(w["points"])
     kw = dict(safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"], poly_params=w["poly_params"],
               polygon=w["polygon"], head_state=w["head_state"], tail_state=w["tail_state"])
