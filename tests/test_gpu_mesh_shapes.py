@@ -104,6 +104,42 @@ def test_c5_negative_gsip_radius_case(built, monkeypatch):
     assert ctx.stats()["gsip_bound_mode"] == 1
 
 
+def test_large_outline_takes_the_global_memory_path(built):
+    """Outlines of more than 1024 vertices do not fit the LDS budget of the solve / round kernels: their edges stay in
+    global memory (the plain Polygon kernel variants).  A 1500-gon with a wavy radius against the oracle: gates +
+    bit-identity per point; and the same answer when a small outline is forced onto that path (SVSDF_POLY_LDS=0)."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    ang = np.linspace(0, 2 * np.pi, 1500, endpoint=False)
+    rad = 2.2 + 0.5 * np.sin(5 * ang) + 0.05 * np.sin(61 * ang)
+    poly = np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
+    w = workload.make(dict(shape="Polygon", N=8, P=300, scenario="star"), minco=svsdf_amd.minco_coeffs)
+    kw = dict(safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"], polygon=poly,
+              head_state=w["head_state"], tail_state=w["tail_state"])
+    ctx = svsdf_amd.SvsdfContext(shape="Polygon", device=0, **kw)
+    ctx.set_points(w["points"])
+    o = orc.Oracle("Polygon", **kw)
+    o.set_traj(w["coeffs"], w["T"])
+    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
+    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost) and _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5
+    o.set_trig_mode(1)
+    sdf, ts, g, _ = ctx.query_points(w["coeffs"], w["T"])
+    osdf, ots, og = o.query(w["points"], nthreads=NT)
+    assert np.array_equal(ts, ots) and np.array_equal(sdf, osdf) and np.array_equal(g, og)
+    # the star outline (77 vertices) through both variants
+    ws, c1, _ = _mk("star", 600)
+    a = c1.query_points(ws["coeffs"], ws["T"])
+    os.environ["SVSDF_POLY_LDS"] = "0"
+    try:
+        _, c2, _ = _mk("star", 600)
+        b = c2.query_points(ws["coeffs"], ws["T"])
+    finally:
+        del os.environ["SVSDF_POLY_LDS"]
+    for u, v in zip(a[:3], b[:3]):
+        assert np.array_equal(u, v)
+
+
 def test_polygon_vertex_limit(built):
     import svsdf_amd
     ang = np.linspace(0, 2 * np.pi, 4096, endpoint=False)

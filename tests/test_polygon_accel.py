@@ -164,6 +164,12 @@ def test_obj_reader_and_errors(built, tmp_path):
     assert {(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)} <= set(map(tuple, np.round(sq, 12)))
     area = 0.5 * abs(np.dot(sq[:, 0], np.roll(sq[:, 1], -1)) - np.dot(sq[:, 1], np.roll(sq[:, 0], -1)))
     assert abs(area - 1.0) < 1e-12
+    # two disjoint solids: two closed loops, the longer one is returned
+    V2 = np.concatenate([V, V[:8] * 0.0 + np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]]) + np.array([20.0, 0.0, -0.5])])
+    quads = np.array([[0, 1, 2, 3], [4, 7, 6, 5], [0, 4, 5, 1], [1, 5, 6, 2], [2, 6, 7, 3], [3, 7, 4, 0]]) + len(V)
+    F2 = np.concatenate([F, np.concatenate([quads[:, [0, 1, 2]], quads[:, [0, 2, 3]]])]).astype(np.int32)
+    both, loops2 = svsdf_amd.mesh_outline(V2, F2)
+    assert loops2 == 2 and np.array_equal(both, b)
     with pytest.raises(svsdf_amd.SvsdfError):
         svsdf_amd.mesh_outline_obj(tmp_path / "missing.obj")
     with pytest.raises(svsdf_amd.SvsdfError):
