@@ -167,7 +167,7 @@ class Runner:
         for _ in range(warmup):
             self.step()
         self.fence()
-        acc = dict(sdf_evals=0, scan_evals=0, solves=0, solve_launches=0, gsip_samples=0, round_scan_evals=0)
+        acc = dict(sdf_evals=0, scan_evals=0, solves=0, solve_launches=0, gsip_samples=0, round_scan_evals=0, speculative_evals=0)
         last = None
         combine_ms = 0.0
         t0 = time.perf_counter()
@@ -286,6 +286,9 @@ def fp64_accounting(acc, steps, solve_ms, solve_ms_serial, round_ms, round_ms_se
     return {"bound": "fp64_valu", "peak": FP64_PEAK_TFLOPS, "peak_no_fma": FP64_NOFMA_TFLOPS, "unit": "TFLOP/s",
             "flop_per_full_eval_nominal": FLOP_PER_EVAL, "flop_per_table_eval_nominal": FLOP_PER_TABLE_EVAL,
             "k_solve_full_evals_per_step": e_full, "k_solve_table_evals_per_step": e_tab, "k_round_table_evals_per_step": e_round,
+            "k_solve_speculative_evals_per_step": acc["speculative_evals"] / steps / ndev,
+            "speculative_note": "of the full evaluations: halving-ladder candidates evaluated behind the accepted one (G per "
+                                "step; the reference's sequential loop would not evaluate them); counted as executed work",
             "k_solve": obj(fl_solve, solve_ms), "k_solve_serialized": obj(fl_solve, solve_ms_serial),
             "k_round": obj(fl_round, round_ms), "k_round_serialized": obj(fl_round, round_ms_serial),
             "whole_evaluation": obj(fl_solve + fl_round, ms_per_step),

@@ -199,7 +199,7 @@ struct svsdf_ctx {
 namespace {
 
 constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 10 + kMaxIter;   // partial | 9 counters | solves per iteration
+constexpr size_t kOutDoubles = kOutPartial + 11 + kMaxIter;   // partial | 9 counters | solves per iteration | round scans | speculative
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -607,6 +607,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.gsip_iterations = (unsigned)st[7];
   ctx->stats.culled_points = st[8];
   ctx->stats.round_scan_evals = st[9 + kMaxIter];
+  ctx->stats.speculative_evals = st[10 + kMaxIter];
   ctx->stats.batches = ctx->nbatch;
   for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
   ctx->have_prev_nsolve = true;
@@ -1133,7 +1134,7 @@ void merge_stats(svsdf_ctx *ctx) {
     const svsdf_stats &a = s->stats;
     t.points += a.points; t.interior_points += a.interior_points; t.solves += a.solves;
     t.gsip_samples += a.gsip_samples; t.sdf_evals += a.sdf_evals; t.scan_evals += a.scan_evals;
-    t.round_scan_evals += a.round_scan_evals;
+    t.round_scan_evals += a.round_scan_evals; t.speculative_evals += a.speculative_evals;
     t.round_ms = std::max(t.round_ms, a.round_ms); t.round_ms_sum = std::max(t.round_ms_sum, a.round_ms_sum);
     t.batches = std::max(t.batches, a.batches);
     t.culled_points += a.culled_points;

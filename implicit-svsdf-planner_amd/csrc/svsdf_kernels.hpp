@@ -63,8 +63,9 @@ constexpr int kChunk = 8;
 struct Chunk { double cx, cy, rb, slack; };  // slack: continuous-path allowance V_c * h for the exact cull (host)
 
 constexpr int kStatSlots = 32;
-struct StatSlot { unsigned long long solves, evals, scan, culled, round_scan, pad[11]; };   // one 128-byte line
-// (solves / evals / scan / culled: k_solve; round_scan: table evaluations of k_round's seed scans)
+struct StatSlot { unsigned long long solves, evals, scan, culled, round_scan, spec, pad[10]; };   // one 128-byte line
+// (solves / evals / scan / culled / spec: k_solve -- spec = ladder candidates evaluated behind the accepted one;
+// round_scan: table evaluations of k_round's seed scans)
 __device__ __forceinline__ StatSlot *stat_slot(StatSlot *slots) {
   return slots + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (kStatSlots - 1));
 }
@@ -352,7 +353,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
   }
   for (int i = threadIdx.x; i < nbatch * kStatSlots; i += blockDim.x) {
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
-    ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull; ss.round_scan = 0ull;
+    ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull; ss.round_scan = 0ull; ss.spec = 0ull;
   }
   if (threadIdx.x == 0) {
     tr->N = N; tr->K = K; tr->dur = dur; tr->exact = exact;
@@ -636,7 +637,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
 template <int SHAPE, int G, int U>
 __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
                                                   double px, double py, int best_k, double best_d, double &x_out,
-                                                  double &fx_out, unsigned &n_eval) {
+                                                  double &fx_out, unsigned &n_eval, unsigned &n_spec) {
   const int li = Grp<G>::li();
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
     PieceCache piece = piece_cache_init();
@@ -740,6 +741,10 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
           if ((fc[u] - fx) < 0) { jacc = li + G * u; xa = xc[u]; fa = fc[u]; }
         const int jbest = Grp<G>::min_i(jacc);
         if (jbest != 0x7fffffff) {
+          // candidates of this block behind the accepted one: evaluated G at a time, never looked at by the sequential loop
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (j0 + li + G * u <= 29 && li + G * u > jbest) ++n_spec;
           const int src = jbest % G;
           x = Grp<G>::bcast((jacc == jbest) ? xa : 0.0, src);
           fx = Grp<G>::bcast((jacc == jbest) ? fa : 0.0, src);
@@ -797,7 +802,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   }
   const TrajL tr = stage_traj(trg, tab_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
   const int li = Grp<G>::li();
-  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0;
+  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0, n_spec = 0;
   // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
   // the launch's cursor.  (All waves of a launch start together: with a fetch first, their 3000 atomics on one address
   // take ~ 12 ns each, one after the other -- the last wave would start ~ 37 us late, in every launch of the chain.)
@@ -837,7 +842,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       if (li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
     } else {
     double x = 0.0, fx = 0.0;
-    descend_from_seed<SHAPE, G, U>(tr, tk, sp, px, py, best_k, best_d, x, fx, n_eval);
+    descend_from_seed<SHAPE, G, U>(tr, tk, sp, px, py, best_k, best_d, x, fx, n_eval, n_spec);
     if (li == 0) {
       out_sdf[slot] = fx;
       out_t[slot] = x;
@@ -846,15 +851,17 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     }  // !culled
     }  // live
   }
-  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tu = n_culled;
+  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tu = n_culled, tp = n_spec;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tu += __shfl_xor(tu, m, 64);
+    tp += __shfl_xor(tp, m, 64);
   }
   if ((threadIdx.x & 63) == 0 && (te || tu)) {
     StatSlot *ss = stat_slot(ctl->stat);
     atomicAdd(&ss->evals, te); atomicAdd(&ss->solves, ts); atomicAdd(&ss->scan, tc);
     if (tu) atomicAdd(&ss->culled, tu);
+    if (tp) atomicAdd(&ss->spec, tp);
   }
 }
 
@@ -1581,11 +1588,11 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
   if (threadIdx.x == 0) {
     double suf = 0.0;
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
-    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0, rs = 0;
+    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0, rs = 0, sp_ = 0;
     for (int b = 0; b < nbatch; ++b) {
       for (int k = 0; k < kStatSlots; ++k) {
         const StatSlot &ss = ctl[b].stat[k];
-        so += ss.solves; ev += ss.evals; sc += ss.scan; cu += ss.culled; rs += ss.round_scan;
+        so += ss.solves; ev += ss.evals; sc += ss.scan; cu += ss.culled; rs += ss.round_scan; sp_ += ss.spec;
       }
       in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
       rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
@@ -1602,6 +1609,7 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
       stats_out[9 + i] = ns;
     }
     stats_out[9 + kMaxIter] = rs;
+    stats_out[10 + kMaxIter] = sp_;
   }
 }
 

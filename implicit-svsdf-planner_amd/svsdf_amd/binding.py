@@ -63,7 +63,8 @@ class Stats(C.Structure):
                 ("gsip_bound_mode", C.c_int), ("bound_mode_decided", C.c_int), ("bound_ratio", C.c_double),
                 ("n_devices", C.c_int), ("combine", C.c_int), ("combine_ms", C.c_double), ("setup_ms", C.c_double),
                 ("piece_time_exact", C.c_int), ("solve_ms_sum", C.c_double), ("round_scan_evals", C.c_ulonglong),
-                ("round_ms", C.c_double), ("round_ms_sum", C.c_double), ("batches", C.c_int), ("plan_settled", C.c_int)]
+                ("round_ms", C.c_double), ("round_ms_sum", C.c_double), ("batches", C.c_int),
+                ("speculative_evals", C.c_ulonglong), ("plan_settled", C.c_int)]
 
 
 class SvsdfError(RuntimeError):

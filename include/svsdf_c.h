@@ -337,6 +337,9 @@ typedef struct svsdf_stats {
   double round_ms;                    /* HIP-event time during which >= 1 k_round launch was executing (profiling on) */
   double round_ms_sum;                /* plain sum of the k_round launch durations (profiling on) */
   int batches;                        /* point batches (concurrent streams) the last evaluation ran as */
+  unsigned long long speculative_evals; /* of sdf_evals: halving-ladder candidates evaluated BEHIND the accepted one (the
+                                          lane group evaluates G candidates per step; the reference's sequential loop
+                                          stops at the accepted one) */
   int plan_settled;                   /* 1 once bound mode, batch count and launch widths are fixed for this point set:
                                          the first evaluations after svsdf_set_points decide them (<= 6 evaluations, all
                                          with identical results); steady-state timing starts here */
