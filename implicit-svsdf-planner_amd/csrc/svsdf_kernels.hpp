@@ -1347,11 +1347,22 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   static_assert(LP == 8 || LP == 32, "lanes per point");
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   extern __shared__ double round_lds[];
-  __shared__ int s_cnt[3][kRoundBlock / LP];   // per point slot: solves, next-list entries, samples
-  __shared__ int s_base[2][kRoundBlock / LP];  // per point slot: solve-list / next-list positions
-  __shared__ unsigned short s_clist[(kRoundBlock / LP) * kMaxCand];   // per point slot: candidate chunks of its round
+  // List positions are handed out per FLUSH, not per block iteration: a point slot buffers what its last LP points requested
+  // (kRoundBlock entries per block = one per thread), then one block scan + one set of atomics places them all.  The block
+  // meets at 4 barriers per LP iterations instead of 3 per iteration -- a block used to wait, every iteration, for its
+  // slowest point (21 sample scans next to a point that only closes its round) and for one lane's serial prefix loop.
+  constexpr int PPB = kRoundBlock / LP;            // point slots per block
+  constexpr int kEnt = kRoundBlock;                // buffered entries: LP iterations x PPB slots
+  constexpr int kWaves = (kRoundBlock + 63) / 64;
+  __shared__ unsigned s_mask[kEnt][NP];            // per entry: requested-sample masks (over the point's lanes)
+  __shared__ int s_a[kEnt];                        // per entry: interior index | push_next << 30; -1: no point
+  __shared__ unsigned short s_emit[kEnt];          // per entry: samples emitted
+  __shared__ int s_off[2][kEnt];                   // per entry: offset in the solve / next list within this flush
+  __shared__ int s_wsum[3][kWaves];
+  __shared__ int s_base[2];
+  __shared__ unsigned short s_clist[PPB * kMaxCand];   // per point slot: candidate chunks of its round
   const int n_act = ctl->n_active[it];
-  const int ppb = blockDim.x / LP;  // points per block
+  const int ppb = blockDim.x / LP;  // points per block (== PPB)
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
@@ -1372,19 +1383,15 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   int *solve = gs.solve + (size_t)start * kMaxSlots;
   const int l = (int)(threadIdx.x & (LP - 1));
   const int hw = (int)(threadIdx.x / LP);
+  const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
   unsigned n_scan = 0;   // table evaluations of the cooperative seed scans (FULL)
   const unsigned lt_mask = (1u << l) - 1u;
-  // block-uniform trip count; lane groups without a point still take part in the barriers
+  int nbuf = 0;          // block iterations buffered since the last flush (block-uniform)
+  // block-uniform trip count; lane groups without a point still take part in the flushes
   for (int e0 = (int)blockIdx.x * ppb; e0 < n_act; e0 += (int)gridDim.x * ppb) {
     const int e = e0 + hw;
     const bool active = e < n_act;
-    int a = 0, n_emit = 0, n_list = 0;
-    size_t ia = 0;
-    bool push_next = false;
-    bool list_me[NP];
-    unsigned mlist[NP];
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) { list_me[ps] = false; mlist[ps] = 0u; }
+    int a = 0;
     RoundOut<NP> ro;
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) { ro.list_me[ps] = false; ro.mlist[ps] = 0u; }
@@ -1394,43 +1401,69 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
       round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, delta, band_delta, res_sdf,
                                    res_t, res_gx, res_gy, n_scan, ro, s_clist + (size_t)hw * kMaxCand, clist_on);
     }
-    ia = (size_t)start + a;
-    push_next = ro.push_next;
-    n_emit = ro.n_emit;
+    if (l == 0) {
+      const int ent = nbuf * PPB + hw;
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) { list_me[ps] = ro.list_me[ps]; mlist[ps] = ro.mlist[ps]; }
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) n_list += __popc(mlist[ps]);
-    // ---- one set of list atomics per block iteration
-    if (l == 0) { s_cnt[0][hw] = n_list; s_cnt[1][hw] = push_next ? 1 : 0; s_cnt[2][hw] = n_emit; }
+      for (int ps = 0; ps < NP; ++ps) s_mask[ent][ps] = ro.mlist[ps];
+      s_a[ent] = active ? (a | (ro.push_next ? (1 << 30) : 0)) : -1;
+      s_emit[ent] = (unsigned short)ro.n_emit;
+    }
+    ++nbuf;
+    const bool last = e0 + (int)gridDim.x * ppb >= n_act;
+    if (nbuf < LP && !last) continue;
+    // ---- flush: one block scan, one set of list atomics, then every point slot writes the entries of its points
     __syncthreads();
-    if (threadIdx.x < 64) {  // one wave: exclusive scans over the <= 128 point slots of the block
-      int t0 = 0, t1 = 0, t2 = 0;
-      for (int h = (int)threadIdx.x; h < ppb; h += 64) { t0 += s_cnt[0][h]; t1 += s_cnt[1][h]; t2 += s_cnt[2][h]; }
+    const int nent = nbuf * PPB;
+    int c0 = 0, c1 = 0, c2 = 0;
+    if ((int)threadIdx.x < nent) {
+      const int av = s_a[threadIdx.x];
+      if (av != -1) {
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) { t0 += __shfl_xor(t0, m, 64); t1 += __shfl_xor(t1, m, 64); t2 += __shfl_xor(t2, m, 64); }
-      int b0 = 0, b1 = 0;
-      if (threadIdx.x == 0) {
-        b0 = t0 ? atomicAdd(&ctl->n_solve[it], t0) : 0;
-        b1 = t1 ? atomicAdd(&ctl->n_active[it + 1], t1) : 0;
-        if (t2) atomicAdd(&ctl->n_seed[it], t2);
-        int r0 = b0, r1 = b1;
-        for (int h = 0; h < ppb; ++h) { s_base[0][h] = r0; s_base[1][h] = r1; r0 += s_cnt[0][h]; r1 += s_cnt[1][h]; }
+        for (int ps = 0; ps < NP; ++ps) c0 += __popc(s_mask[threadIdx.x][ps]);
+        c1 = (av >> 30) & 1;
+        c2 = (int)s_emit[threadIdx.x];
       }
     }
+    int x0 = c0, x1 = c1, x2 = c2;   // inclusive scans over the wave (entry order = thread order); x2: plain sum
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const int y0 = __shfl_up(x0, m, 64), y1 = __shfl_up(x1, m, 64);
+      if (lane >= m) { x0 += y0; x1 += y1; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x2 += __shfl_xor(x2, m, 64);
+    if (lane == 63) { s_wsum[0][wv] = x0; s_wsum[1][wv] = x1; s_wsum[2][wv] = x2; }
     __syncthreads();
-    {
-      int pos = s_base[0][hw];
+    int pre0 = 0, pre1 = 0, tot0 = 0, tot1 = 0, tot2 = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      if (w < wv) { pre0 += s_wsum[0][w]; pre1 += s_wsum[1][w]; }
+      tot0 += s_wsum[0][w]; tot1 += s_wsum[1][w]; tot2 += s_wsum[2][w];
+    }
+    if (threadIdx.x == 0) {
+      s_base[0] = tot0 ? atomicAdd(&ctl->n_solve[it], tot0) : 0;
+      s_base[1] = tot1 ? atomicAdd(&ctl->n_active[it + 1], tot1) : 0;
+      if (tot2) atomicAdd(&ctl->n_seed[it], tot2);
+    }
+    if ((int)threadIdx.x < nent) { s_off[0][threadIdx.x] = pre0 + x0 - c0; s_off[1][threadIdx.x] = pre1 + x1 - c1; }
+    __syncthreads();
+    for (int k = 0; k < nbuf; ++k) {
+      const int ent = k * PPB + hw;
+      const int av = s_a[ent];
+      if (av == -1) continue;
+      const int a2 = av & 0x3fffffff;
+      const size_t ia2 = (size_t)start + a2;
+      int pos = s_base[0] + s_off[0][ent];
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
-        if (list_me[ps]) solve[pos + __popc(mlist[ps] & lt_mask)] = (int)sample_slot(stride, ia, l + LP * ps);
-        pos += __popc(mlist[ps]);
+        const unsigned m = s_mask[ent][ps];
+        if ((m >> l) & 1u) solve[pos + __popc(m & lt_mask)] = (int)sample_slot(stride, ia2, l + LP * ps);
+        pos += __popc(m);
       }
+      if (((av >> 30) & 1) && l == 0) nxt[s_base[1] + s_off[1][ent]] = a2;
     }
-    if (push_next && l == 0) {
-      nxt[s_base[1][hw]] = a;
-    }
-    __syncthreads();
+    __syncthreads();   // the buffers are rewritten by the next iterations
+    nbuf = 0;
   }
   if constexpr (MODE != 0) {
     unsigned long long tc = n_scan;
