@@ -755,8 +755,8 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
       ctx->bt_state = 1;
       ctx->bt_cand[0] = 1;
       ctx->bt_cand[1] = ctx->ub_lazy ? 2 : 4;
-      ctx->bt_ncand = 2;
-      if (!ctx->ub_lazy) { ctx->bt_cand[2] = 3; ctx->bt_ncand = 3; }
+      ctx->bt_cand[2] = 3;
+      ctx->bt_ncand = 3;
     }
   }
   fill_mode_stats(ctx);
