@@ -309,12 +309,15 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
   // with one wave per block that caps the CU at 160 KB / lds waves -- 6 at C3, half of what the kernel's 141 VGPRs
   // allow (3 waves per SIMD) -- so the block grows until LDS no longer binds (measured at C3: 10.7 -> 9.2 ms).
   int blk = ctx->block;
-  if (!ctx->block_env) blk = (lds * 12 <= 160 * 1024) ? 64 : (lds * 6 <= 160 * 1024) ? 128 : 256;
+  const size_t wlds = ladder_lds_bytes(G);   // per wave: the descent state of its 64 / G groups
+  if (!ctx->block_env) blk = ((lds + wlds) * 12 <= 160 * 1024) ? 64 : ((lds + 2 * wlds) * 6 <= 160 * 1024) ? 128 : 256;
+  const size_t lds_tables = (lds + 15) & ~(size_t)15;
+  const size_t lds_total = lds_tables + (size_t)(blk / 64) * wlds;
   const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh};
-  (void)launch_k_solve(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds, st, a);
+  (void)launch_k_solve(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds_total, st, a);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -1012,14 +1015,15 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   // lanes per query: an evaluation is a chain of ~10 dependent solve launches, each a chain of ~100 dependent
   // group steps.  Small shards cannot fill the GPU and are pure latency: wide groups shorten the chains
   // (32 lanes: a whole halving ladder / scan layer per step).  Large shards are throughput: narrow groups waste
-  // fewer lanes.  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
+  // fewer lanes (2 since round 3: the ladders share the wave's lanes anyway, so the width only shapes the scan layers and
+  // the derivative).  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
   ctx->have_prev_nsolve = false;
   ctx->ub_tune = 0;
   ctx->bt_state = 0;
   ctx->ub_ratio = 0.0;
   if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; }
   if (!ctx->G_env) {
-    ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 4;
+    ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : 2;
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
   }
   return SVSDF_OK;
@@ -1677,6 +1681,21 @@ long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, in
     return -1;
   return (long long)h;
 }
+
+#ifdef SVSDF_SITE_STATS
+// diagnostic builds only (tools/site_stats.py): k_solve's per-site execution / lane counters of the last evaluation
+extern "C" int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[12]) {
+  if (!ctx || ctx->host_only || !ctx->subs.empty()) return SVSDF_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return SVSDF_ERR_HIP_BASE;
+  std::vector<BatchCtl> hc(kMaxBatches);
+  if (hipMemcpy(hc.data(), ctx->d_ctl, sizeof(BatchCtl) * kMaxBatches, hipMemcpyDeviceToHost) != hipSuccess) return SVSDF_ERR_HIP_BASE;
+  for (int i = 0; i < 12; ++i) out[i] = 0;
+  for (const BatchCtl &b : hc)
+    for (const StatSlot &sl : b.stat)
+      for (int i = 0; i < 12; ++i) out[i] += sl.pad[i];
+  return SVSDF_OK;
+}
+#endif
 
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
   if (!ctx) return SVSDF_ERR_INVALID;

@@ -30,6 +30,9 @@ namespace svsdf {
 #ifndef SVSDF_SOLVE_WAVES
 #define SVSDF_SOLVE_WAVES 1
 #endif
+#ifndef SVSDF_ELASTIC
+#define SVSDF_ELASTIC 1   // the descent's halving ladders share the wave's lanes (descend_from_seed)
+#endif
 constexpr int kMaxPieces = 64;
 constexpr int kMaxSlots = 24;   // GSIP samples per round: 2, 6, 18, 21, 21, ... (SWM:60-71,105-110)
 constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
@@ -63,7 +66,11 @@ constexpr int kChunk = 8;
 struct Chunk { double cx, cy, rb, slack; };  // slack: continuous-path allowance V_c * h for the exact cull (host)
 
 constexpr int kStatSlots = 32;
+#ifdef SVSDF_SITE_STATS
+struct StatSlot { unsigned long long solves, evals, scan, culled, round_scan, spec, pad[26]; };   // diagnostic build: two lines
+#else
 struct StatSlot { unsigned long long solves, evals, scan, culled, round_scan, spec, pad[10]; };   // one 128-byte line
+#endif
 // (solves / evals / scan / culled / spec: k_solve -- spec = ladder candidates evaluated behind the accepted one;
 // round_scan: table evaluations of k_round's seed scans)
 __device__ __forceinline__ StatSlot *stat_slot(StatSlot *slots) {
@@ -354,6 +361,9 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
   for (int i = threadIdx.x; i < nbatch * kStatSlots; i += blockDim.x) {
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
     ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull; ss.round_scan = 0ull; ss.spec = 0ull;
+#ifdef SVSDF_SITE_STATS
+    for (int j = 0; j < 12; ++j) ss.pad[j] = 0ull;
+#endif
   }
   if (threadIdx.x == 0) {
     tr->N = N; tr->K = K; tr->dur = dur; tr->exact = exact;
@@ -446,6 +456,25 @@ __device__ __forceinline__ bool qs_slot(const QuerySet &qs, int n, long long q, 
   return true;
 }
 
+// -DSVSDF_SITE_STATS (diagnostic builds, tools/site_stats.py): per evaluation site of k_solve -- table scan 0, layers 2-4 1,
+// FD derivative 2, ladder 3 -- the number of wave-level executions (StatSlot::pad[site]) and of lanes that evaluate there
+// (pad[4 + site]): lanes / (64 x executions) is the site's lane occupancy.
+#ifdef SVSDF_SITE_STATS
+#define SVSDF_SITE(cnt, site, evaluates)                                                     \
+  do {                                                                                       \
+    const unsigned long long ex__ = __ballot(1);                                             \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex__) - 1) ++(cnt)[site];              \
+    if (evaluates) ++(cnt)[4 + (site)];                                                      \
+  } while (0)
+#define SVSDF_SITE_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
+// wave-level cycles of a phase (8 scan, 9 layers 2-4, 10 descent), counted once per wave
+#define SVSDF_SITE_CYCLES(cnt, slot, t0) do { if ((threadIdx.x & 63) == 0) (cnt)[slot] += SVSDF_SITE_CLOCK() - (t0); } while (0)
+#else
+#define SVSDF_SITE(cnt, site, evaluates) do { } while (0)
+#define SVSDF_SITE_CLOCK() 0ull
+#define SVSDF_SITE_CYCLES(cnt, slot, t0) do { } while (0)
+#endif
+
 // G lanes cooperate on one query (64/G queries per wave).
 template <int G>
 struct Grp {
@@ -530,7 +559,8 @@ template <int SHAPE, int G, bool LITE = false>
 __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *pose, const Chunk *chunks, int K,
                                             int nch, double px, double py, int prune, double cull_thresh,
                                             double &best_d, int &best_k, bool &culled, unsigned &n_scan,
-                                            const unsigned short *clist = nullptr, int ncl = -1) {
+                                            const unsigned short *clist = nullptr, int ncl = -1,
+                                            unsigned long long *sc = nullptr) {
   const int li = Grp<G>::li();
   best_d = 1e9;   // min_dis initial value (SWM:545)
   best_k = 0x7fffffff;
@@ -542,6 +572,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
 #pragma unroll
     for (int m = 0; m < kChunk / GS; ++m) {
       const int k = c * kChunk + li + GS * m;
+      if (sc) SVSDF_SITE(sc, 0, li < kChunk && k < K);
       if (li < kChunk && k < K) {
         const Pose p = pose[k];
         const double d = sdf_from_pose<SHAPE>(sp, p, px, py);
@@ -634,15 +665,25 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
 // Layers 2-4 of choiceTInit (SWM:557-577) + gradientDescent (SWM:1249-1325) for ONE query by G cooperating lanes,
 // from the layer-1 seed (time tk[best_k], value best_d): the argmin time x and its value fx (all lanes of the group get
 // them).
+//
+// Called by ALL lanes of the wave (`on`: this group has a query): layers 2-4 run per group; the halving ladder of the
+// descent is shared out over the whole wave (SVSDF_ELASTIC, below; wave_lds: this wave's ladder_lds_bytes(G) of LDS).
+// (80-byte rows: 20 dwords, so the rows of 16 groups start in 16 different LDS banks)
+struct alignas(16) LadderState { double px, py, seed, x, fx, prev_x, lo, hi; int sgn, piece, pad_[2]; };   // one group's descent
+__host__ __device__ constexpr size_t ladder_lds_bytes(int G) { return (size_t)(64 / G) * sizeof(LadderState) + 64; }
 template <int SHAPE, int G, int U>
 __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
-                                                  double px, double py, int best_k, double best_d, double &x_out,
-                                                  double &fx_out, unsigned &n_eval, unsigned &n_spec) {
+                                                  double px, double py, bool on, int best_k, double best_d,
+                                                  double &x_out, double &fx_out, unsigned &n_eval, unsigned &n_spec,
+                                                  unsigned long long (&sc)[12], void *wave_lds) {
   const int li = Grp<G>::li();
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
     PieceCache piece = piece_cache_init();
-    double time_seed = tk[best_k];
+    double time_seed = 0.0;
     double min_dis = best_d;
+  const unsigned long long t_lay0 = SVSDF_SITE_CLOCK();
+  if (on) {
+    time_seed = tk[best_k];
 
     // ---- choiceTInit layers 2-4: W = G*U samples per step, lane li takes li, li+G, ...
     constexpr int W = G * U;
@@ -666,6 +707,7 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           d[u] = inf;
+          SVSDF_SITE(sc, 1, t[u] <= loop_terminal);
           if (t[u] <= loop_terminal) { d[u] = sdf_at<SHAPE>(tr, sp, px, py, t[u], piece); ++n_eval; }
         }
         double db = d[0], tb = t[0];
@@ -688,8 +730,152 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
       }
       dt *= 0.1;
     }
+  }  // on
+  SVSDF_SITE_CYCLES(sc, 9, t_lay0);
+  const unsigned long long t_desc0 = SVSDF_SITE_CLOCK();
 
+#if SVSDF_ELASTIC
+    // ---- gradientDescent, the ladder shared out over the wave.  A pass = the FD derivative at x (per group, 2-3
+    // evaluations) + the halving ladder: candidates x - 0.01 * 2^(1-j) * sgn, j = 1 .. 29, the FIRST with f < fx is taken.
+    // The candidates of a ladder do not depend on each other, so any number of them may be evaluated at once, by any
+    // lane: the 64 lanes of the wave are dealt out evenly to the groups whose ladder is still open (16 groups: 4 lanes
+    // each as before; 5 groups: 12 each; one group: its 29 candidates in one step).  Groups of a wave need different
+    // numbers of passes and of ladder steps (site counters, tools/site_stats.py: 46 % of the lanes evaluate at this site
+    // with fixed 4-lane ladders, 85 % so); a group that is done hands its lanes to the others instead of idling.  Same
+    // accepted candidate, bit for bit.
+    // The groups' descent state lives in the wave's LDS rows (one wave reads and writes them in program order: no
+    // barrier): a serving lane reads the state of the group it works for and, if its candidate is the first accepted
+    // one, writes the new (x, fx) back; the owner picks them up at the top of its next pass.  All open ladders of a
+    // wave started their pass together and advance by the same width, so the next candidate index j0 is wave-uniform.
+    {
+      // plain accesses between wavefront-scope fences (compiler ordering; one wave's LDS operations execute in order)
+      LadderState *gs = reinterpret_cast<LadderState *>(wave_lds);
+      unsigned char *srcmap = reinterpret_cast<unsigned char *>(gs + 64 / G);
+      const int lane = (int)(threadIdx.x & 63);
+      const int grp = lane / G;
+      LadderState *mine_gs = gs + grp;
+      // (the descent's clamp [t_min, t_max] follows from time_seed)
+      if (on && li == 0) {
+        mine_gs->px = px; mine_gs->py = py; mine_gs->seed = time_seed; mine_gs->x = time_seed; mine_gs->fx = 0.0;
+        mine_gs->prev_x = 10000000.0;
+        mine_gs->piece = piece.piece; mine_gs->lo = 1.0; mine_gs->hi = 0.0;   // (empty interval: located at first use)
+      }
+      int iter = 0;
+      bool run = on;
+      for (bool first_pass = true;; first_pass = false) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (run) run = iter < 1000 && fabs(mine_gs->x - mine_gs->prev_x) > 1e-16;
+        if (__ballot(run) == 0ull) break;
+        if (run) {
+          // tasks: 0 -> sdf(t1), 1 -> sdf(t2), 2 -> sdf(x) (first pass only)
+          const double x = mine_gs->x, qx = mine_gs->px, qy = mine_gs->py;
+          PieceCache dpc;
+          dpc.piece = mine_gs->piece; dpc.lo = mine_gs->lo; dpc.hi = mine_gs->hi;
+          const int ntask = first_pass ? 3 : 2;
+          const double t1 = dmax(0.0, x - 0.000001);
+          const double t2 = dmin(tr.dur, x + 0.000001);
+          double sdf1 = 0.0, sdf2 = 0.0, f0 = 0.0;
+#pragma unroll
+          for (int base = 0; base < 3; base += G) {
+            if (base < ntask) {
+              const int task = base + li;
+              double d = 0.0;
+              SVSDF_SITE(sc, 2, task < ntask);
+              if (task < ntask) {
+                const double tt = (task == 0) ? t1 : (task == 1) ? t2 : x;
+                d = sdf_at<SHAPE>(tr, sp, qx, qy, tt, dpc);
+                ++n_eval;
+              }
+              if (0 >= base && 0 < base + G) sdf1 = Grp<G>::bcast(d, 0 - base);
+              if (1 >= base && 1 < base + G) sdf2 = Grp<G>::bcast(d, 1 - base);
+              if (2 >= base && 2 < base + G) f0 = Grp<G>::bcast(d, 2 - base);
+            }
+          }
+          const double g = (sdf2 - sdf1) * 500000;
+          if (li == 0) {   // (lane 0 evaluated at t1 = x - 1e-6: its piece interval is the ladder's starting point)
+            mine_gs->sgn = (int)(g > 0) - (int)(g < 0);
+            mine_gs->prev_x = x;
+            mine_gs->piece = dpc.piece; mine_gs->lo = dpc.lo; mine_gs->hi = dpc.hi;
+            if (first_pass) mine_gs->fx = f0;
+          }
+        }
+        bool lad = run;   // this group's ladder is open
+        int j0 = 1;       // next candidate of every open ladder (wave-uniform)
+        for (;;) {
+          const unsigned long long am = __ballot(lad && li == 0);
+          if (am == 0ull) break;
+          const int n_act = __popcll(am);
+#ifdef SVSDF_SITE_STATS
+          if (lane == 0 && n_act == 64 / G) ++sc[11];   // ladder steps with every group's ladder open
+#endif
+          // lanes per open ladder (wave-uniform), this group's number among the open ones, and for every lane the
+          // ladder it works on (a-th open one) and its place in that ladder's step
+          int wd, rank, a, off, src;
+          bool serve;
+          if (n_act == 64 / G) {   // every ladder open: each group works on its own
+            wd = G; rank = grp; a = grp; off = li; src = grp; serve = true;
+          } else {
+            // floor(64 / n) and floor(lane / wd) through the reciprocal: the quotients stay >= 0.5 / 64 away from the
+            // next integer, far more than the reciprocal's error (all n, wd, lane checked: tests/test_elastic_widths.py)
+            wd = min(32, (int)(64.5f * __builtin_amdgcn_rcpf((float)n_act)));
+            rank = __popcll(am & ((1ull << (lane & ~(G - 1))) - 1ull));
+            if (lad && li == 0) srcmap[rank] = (unsigned char)grp;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            a = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)wd));
+            off = lane - a * wd;
+            serve = a < n_act;
+            src = (int)srcmap[serve ? a : 0];
+          }
+          LadderState *S = gs + src;   // the served group's state
+          const double spx = S->px, spy = S->py, sseed = S->seed, sx = S->x, sfx = S->fx;
+          const double ssgn = (double)S->sgn;
+          PieceCache pcs;
+          pcs.piece = S->piece; pcs.lo = S->lo; pcs.hi = S->hi;
+          const double stmin = dmax(0.0, sseed - 3.4), stmax = dmin(sseed + 3.4, tr.dur);
+          const int j = j0 + off;                    // div
+          const double tau = ldexp(0.01, 1 - j);     // alpha halved (div - 1) times: exact
+          const double change = -tau * ssgn;
+          double xc = sx + change;
+          xc = dmax(dmin(xc, stmax), stmin);
+          double fc = inf;
+          const bool mine = serve && j <= 29;
+          SVSDF_SITE(sc, 3, mine);
+          if (mine) { fc = sdf_at<SHAPE>(tr, sp, spx, spy, xc, pcs); ++n_eval; }
+          const unsigned long long accm = __ballot(mine && (fc - sfx) < 0);
+          const unsigned long long wmask = (1ull << wd) - 1ull;
+          if (mine) {
+            const unsigned b = (unsigned)((accm >> (a * wd)) & wmask);
+            if (b != 0u) {
+              const int firsts = __ffs(b) - 1;
+              if (off == firsts) { S->x = xc; S->fx = fc; }   // the first accepted candidate of that ladder
+              if (off > firsts) ++n_spec;   // behind the accepted one: never looked at by the sequential loop
+            }
+          }
+          if (lad) {
+            const unsigned bits = (unsigned)((accm >> (rank * wd)) & wmask);
+            if (bits != 0u) {
+              iter += __ffs(bits);
+              lad = false;
+            } else {
+              const int left = 29 - j0 + 1;
+              iter += (left < wd) ? left : wd;
+              if (j0 + wd > 29) { lad = false; run = false; }   // no candidate accepted: the descent stops (SWM:1318-1321)
+            }
+          }
+          j0 += wd;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      x_out = mine_gs->x;
+      fx_out = mine_gs->fx;
+    }
+#else
+  if (on) {
     // ---- gradientDescent
+    constexpr int W = G * U;
     const double t_min = dmax(0.0, time_seed - 3.4);
     const double t_max = dmin(time_seed + 3.4, tr.dur);
     double x = time_seed, fx = 0.0, prev_x = 10000000.0;
@@ -706,6 +892,7 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
         if (base < ntask) {
           const int task = base + li;
           double d = 0.0;
+          SVSDF_SITE(sc, 2, task < ntask);
           if (task < ntask) {
             const double tt = (task == 0) ? t1 : (task == 1) ? t2 : x;
             d = sdf_at<SHAPE>(tr, sp, px, py, tt, piece);
@@ -731,6 +918,7 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
           xc[u] = x + change;
           xc[u] = dmax(dmin(xc[u], t_max), t_min);
           fc[u] = inf;
+          SVSDF_SITE(sc, 3, j <= 29);
           if (j <= 29) { fc[u] = sdf_at<SHAPE>(tr, sp, px, py, xc[u], piece); ++n_eval; }
         }
         // first accepted div over the W candidates of this step
@@ -759,6 +947,9 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
     }
     x_out = x;
     fx_out = fx;
+  }  // on
+#endif
+  SVSDF_SITE_CYCLES(sc, 10, t_desc0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,7 +966,8 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
 //    accepts (bit-identical result, shorter dependent chain).  getSDF_DOT (SWM:799-806) is
 //    evaluated once per descent pass: x does not change inside the ladder, so the reference's
 //    per-trial re-evaluation returns the same number.
-// LDS: [Polygon edges 5 nverts (kPolygonLds only) | pose table 4K | chunks 4*nch | trajectory 20N+1] doubles.
+// LDS: [Polygon edges 5 nverts (kPolygonLds only) | pose table 4K | chunks 4*nch | trajectory 20N+1] doubles, then
+// ladder_lds_bytes(G) per wave of the block (descent state of its 64 / G groups).
 // ---------------------------------------------------------------------------------------------
 // (Polygon: 172 VGPRs would mean 2 waves per SIMD for a kernel that waits on its candidate-record loads; asking for 3
 // blocks of 4 waves per CU caps it at 168 with two spilled registers: C5 43.3 -> 38.7 ms)
@@ -801,8 +993,12 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) tab_lds[4 * (size_t)K + i] = srcc[i];
   }
   const TrajL tr = stage_traj(trg, tab_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads
+  // per-wave descent state behind the trajectory (16-byte aligned: the tables before it are whole doubles, rounded up)
+  const size_t tables = poly_lds_doubles<SHAPE>(sp.nverts) + 4 * (size_t)K + 4 * (size_t)nch + (size_t)traj_lds_doubles(tr.N);
+  char *wave_lds = reinterpret_cast<char *>(solve_lds + ((tables + 1) & ~(size_t)1)) + (threadIdx.x >> 6) * ladder_lds_bytes(G);
   const int li = Grp<G>::li();
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0, n_spec = 0;
+  unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
   // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
   // the launch's cursor.  (All waves of a launch start together: with a fetch first, their 3000 atomics on one address
   // take ~ 12 ns each, one after the other -- the last wave would start ~ 37 us late, in every launch of the chain.)
@@ -826,30 +1022,31 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       px = qs.qx[slot]; py = qs.qy[slot];
       live = (px == px);  // NaN marks an unused slot (whole group)
     }
-    if (live) {
     // ---- choiceTInit layer 1 over the pose table (or the seed k_round already found for a GSIP sample)
     double best_d = 1e9;
     int best_k = 0x7fffffff;
     bool culled = false;
+    const unsigned long long t_scan0 = SVSDF_SITE_CLOCK();
+    if (live) {
     if (qs.seed_k) {
       best_k = qs.seed_k[slot];
       best_d = qs.seed_d[slot];
     }
     if (!qs.seed_k || best_k < 0) {   // no seed for this query (main points, cheap-bound samples, unscanned lazy samples)
-      scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan);
+      scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan, nullptr, -1,
+                            sc);
     }
-    if (culled) {
-      if (li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
-    } else {
+    if (culled && li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
+    }  // live
+    const bool on = live && !culled;
+    SVSDF_SITE_CYCLES(sc, 8, t_scan0);
     double x = 0.0, fx = 0.0;
-    descend_from_seed<SHAPE, G, U>(tr, tk, sp, px, py, best_k, best_d, x, fx, n_eval, n_spec);
-    if (li == 0) {
+    descend_from_seed<SHAPE, G, U>(tr, tk, sp, px, py, on, best_k, best_d, x, fx, n_eval, n_spec, sc, wave_lds);   // whole wave
+    if (on && li == 0) {
       out_sdf[slot] = fx;
       out_t[slot] = x;
       ++n_solved;
     }
-    }  // !culled
-    }  // live
   }
   unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tu = n_culled, tp = n_spec;
 #pragma unroll
@@ -863,6 +1060,15 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     if (tu) atomicAdd(&ss->culled, tu);
     if (tp) atomicAdd(&ss->spec, tp);
   }
+#ifdef SVSDF_SITE_STATS
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    unsigned long long v = sc[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stat_slot(ctl->stat)->pad[i], v);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

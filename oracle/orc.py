@@ -23,7 +23,8 @@ _dp = C.POINTER(C.c_double)
 class Counters(C.Structure):
     _fields_ = [("sdf_evals", C.c_longlong), ("shape_evals", C.c_longlong),
                 ("solves", C.c_longlong), ("interior_points", C.c_longlong),
-                ("gd_trials", C.c_longlong)]
+                ("gd_trials", C.c_longlong), ("gd_passes", C.c_longlong), ("gd_max_passes", C.c_longlong),
+                ("gd_pass_hist", C.c_longlong * 32)]
 
 
 def build(force=False):

@@ -663,7 +663,9 @@ static void gradient_descent(const orc_ctx *ctx, double t_min, double t_max, con
   int iter = 0, stop = 0;
   double x_candidate, fx_candidate;
   g = 100.0;
+  int passes = 0;
   while (iter < max_iter && !stop && fabs(*x - prev_x) > tol) {
+    passes++;
     if (iter == 0) *fx = sdf_at_time(ctx, px, py, *x);
     g = sdf_dot_at_time(ctx, px, py, *x);
     tau = alpha;
@@ -686,6 +688,9 @@ static void gradient_descent(const orc_ctx *ctx, double t_min, double t_max, con
       if (div == 29) stop = 1;
     }
   }
+  tl_cnt.gd_passes += passes;
+  if (passes > tl_cnt.gd_max_passes) tl_cnt.gd_max_passes = passes;
+  tl_cnt.gd_pass_hist[passes / 4 < 31 ? passes / 4 : 31]++;
 }
 
 /* getSDFofSweptVolume<false,true> SWM:844-866 */
@@ -897,6 +902,9 @@ static void fold_counters(orc_ctx *ctx) {
     ctx->cnt.solves += tl_cnt.solves;
     ctx->cnt.interior_points += tl_cnt.interior_points;
     ctx->cnt.gd_trials += tl_cnt.gd_trials;
+    ctx->cnt.gd_passes += tl_cnt.gd_passes;
+    if (tl_cnt.gd_max_passes > ctx->cnt.gd_max_passes) ctx->cnt.gd_max_passes = tl_cnt.gd_max_passes;
+    for (int i = 0; i < 32; ++i) ctx->cnt.gd_pass_hist[i] += tl_cnt.gd_pass_hist[i];
   }
   memset(&tl_cnt, 0, sizeof(tl_cnt));
 }

@@ -87,6 +87,9 @@ typedef struct orc_counters {
   long long solves;           /* getSDFofSweptVolume<false,true> calls */
   long long interior_points;  /* points entering the GSIP loop */
   long long gd_trials;        /* gradientDescent inner-loop trials */
+  long long gd_passes;        /* gradientDescent outer-loop passes (each: one derivative + one halving ladder) */
+  long long gd_max_passes;    /* most passes of one descent (max over threads) */
+  long long gd_pass_hist[32]; /* descents by passes: bucket min(passes / 4, 31) */
 } orc_counters;
 
 typedef struct orc_ctx orc_ctx;
