@@ -1684,15 +1684,15 @@ long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, in
 
 #ifdef SVSDF_SITE_STATS
 // diagnostic builds only (tools/site_stats.py): k_solve's per-site execution / lane counters of the last evaluation
-extern "C" int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[12]) {
+extern "C" int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[20]) {
   if (!ctx || ctx->host_only || !ctx->subs.empty()) return SVSDF_ERR_INVALID;
   if (hipSetDevice(ctx->device) != hipSuccess) return SVSDF_ERR_HIP_BASE;
   std::vector<BatchCtl> hc(kMaxBatches);
   if (hipMemcpy(hc.data(), ctx->d_ctl, sizeof(BatchCtl) * kMaxBatches, hipMemcpyDeviceToHost) != hipSuccess) return SVSDF_ERR_HIP_BASE;
-  for (int i = 0; i < 12; ++i) out[i] = 0;
+  for (int i = 0; i < 20; ++i) out[i] = 0;
   for (const BatchCtl &b : hc)
     for (const StatSlot &sl : b.stat)
-      for (int i = 0; i < 12; ++i) out[i] += sl.pad[i];
+      for (int i = 0; i < 20; ++i) out[i] += sl.pad[i];
   return SVSDF_OK;
 }
 #endif

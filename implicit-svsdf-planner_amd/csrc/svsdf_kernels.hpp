@@ -362,7 +362,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
     ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull; ss.round_scan = 0ull; ss.spec = 0ull;
 #ifdef SVSDF_SITE_STATS
-    for (int j = 0; j < 12; ++j) ss.pad[j] = 0ull;
+    for (int j = 0; j < 20; ++j) ss.pad[j] = 0ull;
 #endif
   }
   if (threadIdx.x == 0) {
@@ -469,10 +469,13 @@ __device__ __forceinline__ bool qs_slot(const QuerySet &qs, int n, long long q, 
 #define SVSDF_SITE_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 // wave-level cycles of a phase (8 scan, 9 layers 2-4, 10 descent), counted once per wave
 #define SVSDF_SITE_CYCLES(cnt, slot, t0) do { if ((threadIdx.x & 63) == 0) (cnt)[slot] += SVSDF_SITE_CLOCK() - (t0); } while (0)
+// k_round phases (pad[12 ..]: close, candidate list, samples + cheap bound, seed scans, selection, flush, whole wave, staging)
+#define SVSDF_PHASE(cnt, slot, t0) do { if ((threadIdx.x & 63) == 0) { const unsigned long long n__ = SVSDF_SITE_CLOCK(); (cnt)[slot] += n__ - (t0); (t0) = n__; } } while (0)
 #else
 #define SVSDF_SITE(cnt, site, evaluates) do { } while (0)
 #define SVSDF_SITE_CLOCK() 0ull
 #define SVSDF_SITE_CYCLES(cnt, slot, t0) do { } while (0)
+#define SVSDF_PHASE(cnt, slot, t0) do { } while (0)
 #endif
 
 // G lanes cooperate on one query (64/G queries per wave).
@@ -1202,8 +1205,10 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
                                             const GsipState &gs, size_t stride, int start, int a, double delta,
                                             double band_delta, double *__restrict__ res_sdf, double *__restrict__ res_t,
                                             double *__restrict__ res_gx, double *__restrict__ res_gy, unsigned &n_scan,
-                                            RoundOut<(kMaxSlots + LP - 1) / LP> &out, unsigned short *clist, int clist_on) {
+                                            RoundOut<(kMaxSlots + LP - 1) / LP> &out, unsigned short *clist, int clist_on,
+                                            unsigned long long (&rc)[8]) {
   constexpr bool FULL = MODE == 1;
+  unsigned long long tph = SVSDF_SITE_CLOCK();
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
   const int l = (int)(threadIdx.x & (LP - 1));
   const unsigned lt_mask = (1u << l) - 1u;
@@ -1292,6 +1297,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         }
       }
     }
+    SVSDF_PHASE(rc, 0, tph);
     if (open) {
       // ---- candidate chunks of this round: every sample y of the circle |y - p| = r has, for every table pose k of a
       // chunk c,  |y - c| - rb_c <= sdf_k(y) <= |y - c| + rb_c  (rb_c = chunk radius + shape bound R: the shape has a
@@ -1336,6 +1342,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+      SVSDF_PHASE(rc, 1, tph);
       // ---- open a round: lane l takes samples l, l + LP, ...
       double theta = theta0;
       for (int q = 0; q < l; ++q) theta += theta_res;
@@ -1382,6 +1389,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           for (int q = 0; q < LP; ++q) theta += theta_res;
         }
       }
+      SVSDF_PHASE(rc, 2, tph);
       if constexpr (FULL) {
         // Tightest bound layer 1 can give: the sample's own seed (the full pruned scan its solve would start
         // with), found here by 8 cooperating lanes per sample -- LP / 8 samples at a time -- and handed to
@@ -1510,6 +1518,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
           }
       }
+      SVSDF_PHASE(rc, 3, tph);
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) umax = fmax(umax, ub[ps]);
       umax = fmax(umax, Grp<LP>::template xchg<0>(umax));
@@ -1526,6 +1535,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       }
       push_next = true;
       if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = (int)kPhaseEval; }
+      SVSDF_PHASE(rc, 4, tph);
     }
   }
 
@@ -1570,6 +1580,9 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   const int n_act = ctl->n_active[it];
   const int ppb = blockDim.x / LP;  // points per block (== PPB)
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
+  unsigned long long rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  const unsigned long long t_wave0 = SVSDF_SITE_CLOCK();
+  unsigned long long tfl = t_wave0;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
   stage_poly_edges<SHAPE>(sp, round_lds);
@@ -1583,6 +1596,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) tab_lds[4 * (size_t)K + i] = srcc[i];
   }
   __syncthreads();
+  SVSDF_PHASE(rc, 7, tfl);
   const int start = ctl->start;
   const int *cur = gs.list[it & 1] + start;
   int *nxt = gs.list[(it + 1) & 1] + start;
@@ -1605,7 +1619,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     if (active) {
       a = cur[e];
       round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, delta, band_delta, res_sdf,
-                                   res_t, res_gx, res_gy, n_scan, ro, s_clist + (size_t)hw * kMaxCand, clist_on);
+                                   res_t, res_gx, res_gy, n_scan, ro, s_clist + (size_t)hw * kMaxCand, clist_on, rc);
     }
     if (l == 0) {
       const int ent = nbuf * PPB + hw;
@@ -1618,6 +1632,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     const bool last = e0 + (int)gridDim.x * ppb >= n_act;
     if (nbuf < LP && !last) continue;
     // ---- flush: one block scan, one set of list atomics, then every point slot writes the entries of its points
+    tfl = SVSDF_SITE_CLOCK();
     __syncthreads();
     const int nent = nbuf * PPB;
     int c0 = 0, c1 = 0, c2 = 0;
@@ -1669,8 +1684,16 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
       if (((av >> 30) & 1) && l == 0) nxt[s_base[1] + s_off[1][ent]] = a2;
     }
     __syncthreads();   // the buffers are rewritten by the next iterations
+    SVSDF_PHASE(rc, 5, tfl);
     nbuf = 0;
   }
+#ifdef SVSDF_SITE_STATS
+  if ((threadIdx.x & 63) == 0) {
+    rc[6] = SVSDF_SITE_CLOCK() - t_wave0;
+    StatSlot *ss = stat_slot(ctl->stat);
+    for (int i = 0; i < 8; ++i) if (rc[i]) atomicAdd(&ss->pad[12 + i], rc[i]);
+  }
+#endif
   if constexpr (MODE != 0) {
     unsigned long long tc = n_scan;
 #pragma unroll

@@ -28,7 +28,7 @@ for cfg in cfgs:
         if c.stats().get("plan_settled", 1):
             break
     c.eval_penalty(w["coeffs"], w["T"])
-    out = (C.c_ulonglong * 12)()
+    out = (C.c_ulonglong * 20)()
     c.L.svsdf_debug_site_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     rc = c.L.svsdf_debug_site_stats(c.ctx, out)
     assert rc == 0, rc
@@ -41,3 +41,8 @@ for cfg in cfgs:
     cyc = [out[8], out[9], out[10]]
     print("  wave cycles: scan %.3e  layers %.3e  descent %.3e  (shares %s); ladder steps with all groups open: %d" % (
         cyc[0], cyc[1], cyc[2], " / ".join("%.2f" % (c / max(sum(cyc), 1)) for c in cyc), out[11]))
+    names = ["close", "candidate list", "samples + cheap bound", "seed scans", "selection", "flush", "whole wave", "staging"]
+    tot = max(out[18], 1)
+    print("  k_round wave cycles: " + ", ".join("%s %.3e (%.2f)" % (n, out[12 + i], out[12 + i] / tot) for i, n in enumerate(names)))
+    st = c.stats()
+    print("  ", {k: st[k] for k in ("solves", "sdf_evals", "scan_evals", "round_scan_evals", "gsip_bound_mode", "batches")})
