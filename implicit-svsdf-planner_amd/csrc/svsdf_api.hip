@@ -124,7 +124,7 @@ struct svsdf_ctx {
   // tuning (env SVSDF_G / SVSDF_G_LATE / SVSDF_PRUNE / SVSDF_BLOCK / SVSDF_BATCHES)
   int G = 0 /* 0 = by shard size */, G_late = 8, prune = 1, block = 64, want_batches = 0, waves_per_cu = 16;
   bool block_env = false;      // env SVSDF_BLOCK pins the solve kernel's block size (default: by LDS footprint)
-  int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 2, delta_all_iter = 5;
+  int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 3, delta_all_iter = 5;
   int n_cu = 256;
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
@@ -339,8 +339,10 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
   const double delta = (it >= all_it) ? 1e300 : sel;
   const double band_delta = (it >= all_it) ? 1e300 : ctx->select_delta;   // lazy mode: cheap-bound band that gets scanned
-  // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per
-  // point; later rounds have 18-21 samples: 32 lanes per point (either handles any count)
+  // iterations 0 and 1 are (almost always) GSIP rounds 1 and 2 with 2 and 6 samples: 8 lanes per point; later rounds have
+  // 18-21 samples: 32 lanes per point (either handles any count).  Iteration 2 (18 samples, still every interior point
+  // active: throughput, not latency) also runs faster with 8 lanes and three sample passes per point -- measured round 3,
+  // SVSDF_ROUND_LP8_ITERS 2 / 3 / 4 / 6 / all: C3 6.15 / 5.97 / 6.12 / 6.33 / 6.45 ms, NS 7.49 / 7.24 / 7.21 / 7.31 / 7.58
   const int lp = (it < ctx->round_lp8_iters) ? 8 : 32;
   const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, (long long)(256 * 16 * 64) / kRoundBlock);
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it, delta,
