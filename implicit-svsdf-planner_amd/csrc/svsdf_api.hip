@@ -1488,13 +1488,14 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
       hipMalloc((void **)&ctx->d_out, kOutDoubles * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_out, kOutDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
     return bail("device allocation failed");
-  if (hipMemset(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl) + 8 * 8 * (kMaxIter + 4)) != hipSuccess) return bail("hipMemset failed");
+  // (on the context's own stream: it is non-blocking, a null-stream memset would not be ordered with its kernels)
+  if (hipMemsetAsync(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl) + 8 * 8 * (kMaxIter + 4), ctx->stream) != hipSuccess) return bail("hipMemset failed");
   {  // shape bound radius R with sdf_shape(q) >= |q| - R for every q: the shape's circumradius about the body origin
      // (analytic, per shape; shape_circumradius above) plus the length of its offset (Shape.hpp:281-294).  The polar
      // sample of |q| - sdf(q) (k_rbound, out to 60 m) is kept as a self-check of that bound, not as its source.
     const double r0 = shape_circumradius(cfg->shape_id, ctx->poly_xy.data(), sp.nverts);
     const double analytic = (r0 + std::hypot(sp.tx, sp.ty)) * (1.0 + 1e-12) + 1e-6;
-    if (hipMemset(ctx->d_out, 0, sizeof(double)) != hipSuccess) return bail("hipMemset failed");
+    if (hipMemsetAsync(ctx->d_out, 0, sizeof(double), ctx->stream) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;
     const unsigned grid = (unsigned)((nrad * nang + kBlock - 1) / kBlock);
     (void)launch_k_rbound(cfg->shape_id, grid, ctx->stream, ctx->sp, 60.0, nrad, nang, ctx->d_out);
