@@ -31,6 +31,7 @@
 #include "svsdf_launch.hpp"
 #include "svsdf_lbfgs.hpp"
 #include "svsdf_mesh.hpp"
+#include "svsdf_contour.hpp"
 #include "svsdf_minco.hpp"
 #include "svsdf_points.hpp"
 
@@ -556,6 +557,37 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
   for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
   ctx->it_done = ctx->first_iters;
   return join_batches(ctx);
+}
+
+// The swept-volume implicit function alone: getSDFofSweptVolume<false,true> (SWM:844-866) = min over t of the shape SDF,
+// for every resident point, in the sorted shard order -- the main solve without cull, classification and GSIP rounds
+// (svsdf_swept_outline: the zero set only needs the sign and a Lipschitz value next to it).
+int swept_field(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *sdf_sorted) {
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  if (!ctx->points_set) return fail(ctx, SVSDF_ERR_NO_POINTS, "svsdf_set_points has not been called");
+  if (ctx->P == 0) return SVSDF_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->ev_used = 0;
+  ctx->refine_events.clear();
+  ctx->round_events.clear();
+  ctx->stats = svsdf_stats{};
+  ctx->stats.points = ctx->P;
+  int rc = upload_traj(ctx, N, coeffs, T);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
+  for (int b = 0; b < ctx->nbatch; ++b) {
+    hipStream_t st = ctx->bstream[b];
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_prep, 0));
+    QuerySet qm{};
+    qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
+    qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
+    launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctx->d_ctl + b, 0);
+  }
+  rc = join_batches(ctx);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(sdf_sorted, ctx->d_sdf, ctx->P * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVSDF_OK;
 }
 
 // assemble + reduce + k_finish on the main stream, one D2H of [partial | counters], sync.
@@ -1938,6 +1970,85 @@ int svsdf_mesh_outline_obj(const char *obj_path, double z0, double *xy_out, size
   if (!svsdf_host::mesh_outline(V.data(), V.size() / 3, F.data(), F.size() / 3, z0, xy, loops))
     return fail(nullptr, SVSDF_ERR_INVALID, "svsdf_mesh_outline_obj: no closed cross-section at z0");
   return outline_out(xy, xy_out, capacity_verts, count);
+}
+
+// ---- swept-volume outline (what sw_calculate.cpp / SWM:321-336 produce for visual validation) ----------
+int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double cell, double margin,
+                        double *xy_out, size_t capacity_verts, size_t *n_verts, int *loop_sizes, size_t capacity_loops,
+                        size_t *n_loops, svsdf_outline_stats *stats_out) {
+  if (!ctx || !coeffs || !T || !n_verts || !n_loops) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: null argument");
+  if (N < 1 || N > kMaxPieces || !(cell > 0.0) || !std::isfinite(cell) || !std::isfinite(margin))
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: N, cell or margin out of range");
+  const svsdf_ctx *base = ctx->subs.empty() ? ctx : ctx->subs[0];
+  if (base->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  // bounding box of the path (body origin), grown by the shape's bound radius: the swept volume lies inside
+  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  for (int i = 0; i < N; ++i) {
+    if (!(T[i] > 0.0) || !std::isfinite(T[i])) return fail(ctx, SVSDF_ERR_NONFINITE, "svsdf_swept_outline: bad duration");
+    for (int q = 0; q <= 32; ++q) {
+      const double sl = T[i] * (double)q / 32.0;
+      for (int d = 0; d < 2; ++d) {
+        double v = 0.0;
+        for (int k = 5; k >= 0; --k) v = v * sl + coeffs[(size_t)d * 6 * N + (size_t)i * 6 + k];
+        if (!std::isfinite(v)) return fail(ctx, SVSDF_ERR_NONFINITE, "svsdf_swept_outline: non-finite trajectory");
+        lo[d] = std::min(lo[d], v); hi[d] = std::max(hi[d], v);
+      }
+    }
+  }
+  // (a quintic between samples 1/32 of a piece apart can leave the sampled box by a little: one more bound radius)
+  const double grow = 2.0 * base->r_bound + std::max(margin, 0.0) + 4.0 * cell;
+  svsdf_host::ContourGrid g;
+  g.h = cell;
+  g.levels = 4;
+  g.x0 = lo[0] - grow; g.y0 = lo[1] - grow;
+  const double wx = (hi[0] - lo[0]) + 2.0 * grow, wy = (hi[1] - lo[1]) + 2.0 * grow;
+  if (wx / cell > 1e6 || wy / cell > 1e6) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: more than 1e6 cells per side");
+  g.nx = (long long)std::ceil(wx / cell); g.ny = (long long)std::ceil(wy / cell);
+  // a private single-device context with the same shape and weights: the caller's resident cloud stays as it is
+  svsdf_config c = base->cfg;
+  c.n_devices = 0; c.rank = 0; c.world_size = 1; c.combine = SVSDF_COMBINE_AUTO; c.device = base->device;
+  c.polygon_xy = base->poly_xy.empty() ? nullptr : base->poly_xy.data();
+  c.polygon_nverts = (int)(base->poly_xy.size() / 2);
+  svsdf_ctx *tmp = svsdf_create(&c);
+  if (!tmp) return fail(ctx, SVSDF_ERR_INVALID, std::string("svsdf_swept_outline: ") + svsdf_last_error_string(nullptr));
+  std::vector<double> xyz, sdf;
+  std::vector<long long> idx;
+  const svsdf_host::FieldEval eval = [&](const std::vector<double> &xy, std::vector<double> &val) -> int {
+    const size_t P = xy.size() / 2;
+    xyz.resize(3 * P);
+    for (size_t k = 0; k < P; ++k) { xyz[3 * k] = xy[2 * k]; xyz[3 * k + 1] = xy[2 * k + 1]; xyz[3 * k + 2] = 0.0; }
+    int rc = svsdf_set_points(tmp, xyz.data(), P);
+    if (rc) return rc;
+    if (svsdf_num_points(tmp) != P) return SVSDF_ERR_INVALID;
+    sdf.resize(P); idx.resize(P);
+    rc = swept_field(tmp, N, coeffs, T, sdf.data());
+    if (rc) return rc;
+    rc = svsdf_shard_indices(tmp, idx.data());
+    if (rc) return rc;
+    val.assign(P, 0.0);
+    for (size_t k = 0; k < P; ++k) val[(size_t)idx[k]] = sdf[k];
+    return 0;
+  };
+  std::vector<double> xy;
+  std::vector<int> loops;
+  svsdf_host::ContourStats st;
+  const int rc = svsdf_host::swept_contour(g, eval, 1.5, xy, loops, &st);
+  const std::string tmp_err = rc ? svsdf_last_error_string(tmp) : "";
+  svsdf_destroy(tmp);
+  if (rc) return fail(ctx, rc > 0 ? rc : SVSDF_ERR_INVALID, "svsdf_swept_outline: evaluation failed: " + tmp_err);
+  *n_verts = xy.size() / 2;
+  *n_loops = loops.size();
+  if (stats_out) {
+    stats_out->nodes_evaluated = st.nodes_evaluated; stats_out->dense_nodes = st.dense_nodes;
+    stats_out->cells_marched = st.cells_marched; stats_out->batches = st.batches; stats_out->open_chains = st.open_chains;
+  }
+  if (xy_out && loop_sizes) {
+    if (capacity_verts < xy.size() / 2 || capacity_loops < loops.size())
+      return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: output capacity too small (query with xy_out = NULL first)");
+    std::copy(xy.begin(), xy.end(), xy_out);
+    std::copy(loops.begin(), loops.end(), loop_sizes);
+  }
+  return SVSDF_OK;
 }
 
 // ---- host MINCO helpers --------------------------------------------------------------------------

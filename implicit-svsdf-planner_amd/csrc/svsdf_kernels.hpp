@@ -474,8 +474,8 @@ __device__ __forceinline__ bool qs_slot(const QuerySet &qs, int n, long long q, 
 #else
 #define SVSDF_SITE(cnt, site, evaluates) do { } while (0)
 #define SVSDF_SITE_CLOCK() 0ull
-#define SVSDF_SITE_CYCLES(cnt, slot, t0) do { } while (0)
-#define SVSDF_PHASE(cnt, slot, t0) do { } while (0)
+#define SVSDF_SITE_CYCLES(cnt, slot, t0) do { (void)(t0); } while (0)
+#define SVSDF_PHASE(cnt, slot, t0) do { (void)(t0); } while (0)
 #endif
 
 // G lanes cooperate on one query (64/G queries per wave).

@@ -13,6 +13,7 @@ SHAPES = ["sdUnevenCapsule", "sdCutDisk", "sdTrapezoid", "sdRhombus", "star", "s
 SHAPE_ID = {n: i for i, n in enumerate(SHAPES)}
 
 _dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
 
 # every symbol include/svsdf_c.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -27,7 +28,7 @@ EXPORTS = [
     "svsdf_check_sub_sw_collision", "svsdf_shape_kernels",
     "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
-    "svsdf_mesh_outline", "svsdf_mesh_outline_obj",
+    "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline",
 ]
 
 
@@ -65,6 +66,11 @@ class Stats(C.Structure):
                 ("piece_time_exact", C.c_int), ("solve_ms_sum", C.c_double), ("round_scan_evals", C.c_ulonglong),
                 ("round_ms", C.c_double), ("round_ms_sum", C.c_double), ("batches", C.c_int),
                 ("speculative_evals", C.c_ulonglong), ("plan_settled", C.c_int)]
+
+
+class OutlineStats(C.Structure):
+    _fields_ = [("nodes_evaluated", C.c_ulonglong), ("dense_nodes", C.c_ulonglong), ("cells_marched", C.c_ulonglong),
+                ("batches", C.c_ulonglong), ("open_chains", C.c_int)]
 
 
 class SvsdfError(RuntimeError):
@@ -148,6 +154,9 @@ def lib():
     L.svsdf_mesh_outline.argtypes = [_dp, C.c_size_t, _ip, C.c_size_t, C.c_double, _dp, C.c_size_t,
                                      C.POINTER(C.c_size_t), _ip]
     L.svsdf_mesh_outline_obj.argtypes = [C.c_char_p, C.c_double, _dp, C.c_size_t, C.POINTER(C.c_size_t), _ip]
+    L.svsdf_swept_outline.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, C.c_size_t,
+                                      C.POINTER(C.c_size_t), _ip, C.c_size_t, C.POINTER(C.c_size_t),
+                                      C.POINTER(OutlineStats)]
     _LIB = L
     return L
 
@@ -475,6 +484,27 @@ class SvsdfContext:
         return f, g
 
     # ---- diagnostics ----
+    def swept_outline(self, coeffs, T, cell=0.05, margin=0.0):
+        """Boundary of the swept volume's z = 0 section (svsdf_swept_outline; what the reference's sw_calculate /
+        calculateSwept are for): list of (n_i, 2) closed polylines, inside on the left, + the work statistics."""
+        T = _f64(T)
+        N = len(T)
+        cm = _colmajor(coeffs)
+        nv, nl, st = C.c_size_t(), C.c_size_t(), OutlineStats()
+        self._chk(self.L.svsdf_swept_outline(self.ctx, N, _p(cm), _p(T), float(cell), float(margin), None, 0,
+                                             C.byref(nv), None, 0, C.byref(nl), C.byref(st)), "svsdf_swept_outline")
+        xy = np.zeros((nv.value, 2))
+        sizes = np.zeros(max(nl.value, 1), dtype=np.int32)
+        if nv.value:
+            self._chk(self.L.svsdf_swept_outline(self.ctx, N, _p(cm), _p(T), float(cell), float(margin), _p(xy), nv.value,
+                                                 C.byref(nv), sizes.ctypes.data_as(_ip), nl.value, C.byref(nl),
+                                                 C.byref(st)), "svsdf_swept_outline")
+        loops, off = [], 0
+        for n in sizes[:nl.value]:
+            loops.append(xy[off:off + int(n)].copy())
+            off += int(n)
+        return loops, {k: getattr(st, k) for k, _ in OutlineStats._fields_}
+
     def query_points(self, coeffs, T):
         """Per-point (sdf, t*, grad_xy) in the ORIGINAL order of the points given to set_points
         (world_size == 1) or of this rank's shard (see shard_indices)."""

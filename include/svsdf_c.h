@@ -293,6 +293,29 @@ int svsdf_mesh_outline(const double *V, size_t nv, const int *F, size_t nf, doub
 int svsdf_mesh_outline_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *count,
                            int *loops);
 
+/* ---- swept-volume outline -------------------------------------------------------------------------------
+ * What the reference's (unused) swept-volume surface extraction is for -- SweptVolumeManager::calculateSwept
+ * (sw_manager.hpp:321-336) -> sw_calculate::calculation / getmesh (sw_calculate.cpp:4-305): a sparse-voxel continuation
+ * with one serial gradient descent per voxel corner, then igl::marching_cubes; shown by vis->visMesh -- for this
+ * planar planner: the boundary of the swept volume's z = 0 section, i.e. the zero set of the swept-volume implicit
+ * function min over t of the shape SDF (getSDFofSweptVolume<false,true>, SWM:844-866: the hot path's argmin solve; the
+ * reference's calculateSwept marches the same function, its scalarFunc SWM:1426-1446; the sign is the sign of the value
+ * the optimizer is penalised with, SWM:921), as closed polylines with the inside on their left (outer boundaries
+ * counter-clockwise, holes clockwise).  Batched on the GPU: a hierarchical narrow band
+ * (coarse nodes first, then only cells whose four corners all lie within 1.5 cell diagonals of zero or change sign; cells across a found crossing are added until every chain closes) and marching
+ * squares over the finest band cells of size `cell`; runs in a private context, the caller's resident cloud and launch
+ * plan are untouched.  margin >= 0 widens the searched box (path bounding box + 2 shape bound radii + margin).
+ * xy_out (interleaved, all loops one after the other) / loop_sizes (vertices per loop) may both be NULL to query the
+ * counts.  stats (may be NULL): nodes evaluated vs what a dense grid of that cell size holds; open_chains > 0 means the
+ * zero set left the searched box. */
+typedef struct svsdf_outline_stats {
+  unsigned long long nodes_evaluated, dense_nodes, cells_marched, batches;
+  int open_chains;
+} svsdf_outline_stats;
+int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double cell, double margin,
+                        double *xy_out, size_t capacity_verts, size_t *n_verts, int *loop_sizes, size_t capacity_loops,
+                        size_t *n_loops, svsdf_outline_stats *stats);
+
 /* ---- host-side MINCO helpers (MNC:397-655) ------------------------------------------------------- */
 /* waypoints inPs: 3 x (N-1) col-major; out coeffs (6N) x 3 col-major. */
 int svsdf_minco_coeffs(const double head_state[9], const double tail_state[9], int N,
