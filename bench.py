@@ -50,6 +50,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip ta
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector peak = 1/2 of the 157.3 TF FP32 vector figure
 BYTES_PER_POINT = 24.0     # algorithmic bytes per query point per evaluation (3 x f64)
 FP64_NOFMA_TFLOPS = 39.3   # the same VALU rate without FMA (the parity build is -ffp-contract=off: one flop per lane-op)
+FP64_NOFMA_MEASURED_TFLOPS = 31.6   # what this part sustains on v_mul_f64 + v_add_f64 chains (tools/experiments/fp64_peak.hip,
+                                    # profiles/r03_fp64_peak.txt); reported beside the nominal figures, never instead of them
 FLOP_PER_EVAL = 150.0      # nominal FP64 flop per full SDF-at-time evaluation: polynomial 36 + sincos ~60 + transform 10 +
                            # shape ~45
 FLOP_PER_TABLE_EVAL = 55.0 # a layer-1 TABLE evaluation (pose from the LDS table): transform 10 + shape ~45 only
@@ -283,7 +285,8 @@ def fp64_accounting(acc, steps, solve_ms, solve_ms_serial, round_ms, round_ms_se
     def obj(fl, ms):
         return {"achieved": tf(fl, ms), "frac": tf(fl, ms) / FP64_PEAK_TFLOPS, "frac_of_no_fma_ceiling": tf(fl, ms) / FP64_NOFMA_TFLOPS,
                 "ms": ms, "gflop": fl / 1e9}
-    return {"bound": "fp64_valu", "peak": FP64_PEAK_TFLOPS, "peak_no_fma": FP64_NOFMA_TFLOPS, "unit": "TFLOP/s",
+    return {"bound": "fp64_valu", "peak": FP64_PEAK_TFLOPS, "peak_no_fma": FP64_NOFMA_TFLOPS,
+            "peak_no_fma_measured": FP64_NOFMA_MEASURED_TFLOPS, "unit": "TFLOP/s",
             "flop_per_full_eval_nominal": FLOP_PER_EVAL, "flop_per_table_eval_nominal": FLOP_PER_TABLE_EVAL,
             "k_solve_full_evals_per_step": e_full, "k_solve_table_evals_per_step": e_tab, "k_round_table_evals_per_step": e_round,
             "k_solve_speculative_evals_per_step": acc["speculative_evals"] / steps / ndev,
