@@ -212,6 +212,31 @@ inline int swept_contour(ContourGrid g, const FieldEval &f, double slack, std::v
   return 0;
 }
 
+// Side surface of the extrusion of closed polylines over z in [z0, z1] (what the reference's marching-cubes mesh of an
+// extruded slab's sweep shows, SWM:321-336 / vis->visMesh): per loop of n vertices 2n mesh vertices (bottom ring, then top
+// ring) and 2n triangles, normals away from the inside (the loops have the inside on their left).  V: 3 doubles per
+// vertex, F: 3 zero-based indices per triangle.
+inline void extrude_outline(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1,
+                            std::vector<double> &V, std::vector<int> &F) {
+  V.clear();
+  F.clear();
+  size_t off = 0;
+  for (size_t l = 0; l < n_loops; ++l) {
+    const int n = loop_sizes[l];
+    const int base = (int)(V.size() / 3);
+    for (int ring = 0; ring < 2; ++ring)
+      for (int k = 0; k < n; ++k) {
+        V.push_back(xy[2 * (off + k)]); V.push_back(xy[2 * (off + k) + 1]); V.push_back(ring ? z1 : z0);
+      }
+    for (int k = 0; k < n; ++k) {
+      const int a0 = base + k, b0 = base + (k + 1) % n, a1 = a0 + n, b1 = b0 + n;
+      F.push_back(a0); F.push_back(b0); F.push_back(b1);
+      F.push_back(a0); F.push_back(b1); F.push_back(a1);
+    }
+    off += (size_t)n;
+  }
+}
+
 // signed area of a closed polyline (> 0: counter-clockwise)
 inline double polyline_area(const double *xy, int n) {
   double a = 0.0;

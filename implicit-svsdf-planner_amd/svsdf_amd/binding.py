@@ -28,7 +28,7 @@ EXPORTS = [
     "svsdf_check_sub_sw_collision", "svsdf_shape_kernels",
     "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
-    "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline",
+    "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline", "svsdf_outline_extrude",
 ]
 
 
@@ -215,6 +215,25 @@ def mesh_outline_obj(path, z0=0.0):
     xy = np.zeros((n.value, 2))
     lib().svsdf_mesh_outline_obj(str(path).encode(), float(z0), _p(xy), n.value, C.byref(n), C.byref(loops))
     return xy, loops.value
+
+
+def outline_extrude(loops, z0=-0.5, z1=0.5):
+    """Side surface of the extrusion of closed polylines (svsdf_outline_extrude): V (nv, 3), F (nf, 3).  Host only."""
+    xy = _f64(np.vstack(loops))
+    sizes = np.ascontiguousarray([len(lp) for lp in loops], dtype=np.int32)
+    nv, nf = C.c_size_t(), C.c_size_t()
+    L = lib()
+    L.svsdf_outline_extrude.argtypes = [_dp, _ip, C.c_size_t, C.c_double, C.c_double, _dp, C.c_size_t,
+                                        C.POINTER(C.c_size_t), _ip, C.c_size_t, C.POINTER(C.c_size_t)]
+    rc = L.svsdf_outline_extrude(_p(xy), sizes.ctypes.data_as(_ip), len(sizes), z0, z1, None, 0, C.byref(nv), None, 0,
+                                 C.byref(nf))
+    if rc:
+        raise SvsdfError(f"svsdf_outline_extrude failed: {rc}")
+    V = np.zeros((nv.value, 3))
+    F = np.zeros((nf.value, 3), dtype=np.int32)
+    L.svsdf_outline_extrude(_p(xy), sizes.ctypes.data_as(_ip), len(sizes), z0, z1, _p(V), nv.value, C.byref(nv),
+                            F.ctypes.data_as(_ip), nf.value, C.byref(nf))
+    return V, F
 
 
 def forward_T(tau):

@@ -7,6 +7,8 @@
 // `--reconfig`: after the first evaluation the public member safety_hor is edited (x 1.5) like the reference's members
 // can be, and the callback is evaluated again (the mirror rebuilds its context): cost and cost_pos of the second call
 // follow.  An inputdata whose stem the shape registry does not know is read as an .obj mesh (z = 0 outline -> Polygon).
+// `--swept`: calculateSwept for the trajectory x (cell 0.1): rc, mesh vertices, triangles, loops, outline vertices and the
+// sums of their coordinates follow.
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -58,6 +60,17 @@ int main(int argc, char **argv) {
     opt.safety_hor = 1.5 * sh;
     const double f2 = eval(&opt, x.data(), g.data(), n);
     std::printf("%.17g %.17g\n", f2, opt.cost_pos);
+  }
+  if (argc > 1 && std::string(argv[1]) == "--swept") {
+    // SweptVolumeManager::calculateSwept(U_, G_) call shape (SWM:321-336): mesh of the swept volume for the trajectory x
+    std::vector<double> T(N), coeffs(18 * (size_t)N), U, xy;
+    std::vector<int> G, sizes;
+    svsdf_forward_T(x.data(), T.data(), N);
+    if (svsdf_minco_coeffs(hs, ts, N, x.data() + N, T.data(), coeffs.data()) != SVSDF_OK) return 3;
+    const int rc = opt.calculateSwept(T.data(), coeffs.data(), N, U, G, 0.1, -0.5, 0.5, &xy, &sizes);
+    double sx = 0.0, sy = 0.0;
+    for (size_t k = 0; k < xy.size() / 2; ++k) { sx += xy[2 * k]; sy += xy[2 * k + 1]; }
+    std::printf("%d %zu %zu %zu %zu %.17g %.17g\n", rc, U.size() / 3, G.size() / 3, sizes.size(), xy.size() / 2, sx, sy);
   }
   if (argc > 1 && std::string(argv[1]) == "--optimize") {
     // optimize_traj_lmbm(initS, finalS, opt_x, N, traj) call shape of plan_manager.cpp:176

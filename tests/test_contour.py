@@ -59,3 +59,23 @@ def test_band_gives_the_dense_result_with_a_fraction_of_the_nodes(harness, field
     # same cells marched where the zero set is -> the very same vertices (crossing points depend on two node values only)
     assert sorted(band["loops"]) == sorted(dense["loops"])
     assert band["sx"] == pytest.approx(dense["sx"], abs=1e-9) and band["sy"] == pytest.approx(dense["sy"], abs=1e-9)
+
+
+def test_outline_extrusion_is_a_wall_with_outward_normals(built):
+    """svsdf_outline_extrude (host only): a counter-clockwise square with a clockwise square hole."""
+    import numpy as np
+    import svsdf_amd
+    outer = np.array([[0, 0], [4, 0], [4, 4], [0, 4]], dtype=float)            # inside on the left
+    hole = np.array([[1, 1], [1, 3], [3, 3], [3, 1]], dtype=float)             # clockwise
+    V, F = svsdf_amd.outline_extrude([outer, hole], z0=-0.5, z1=0.5)
+    assert V.shape == (16, 3) and F.shape == (16, 3)
+    assert set(np.unique(V[:, 2])) == {-0.5, 0.5}
+    tri = V[F]
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert np.allclose(nrm[:, 2], 0.0)                                         # vertical walls
+    assert np.isclose(0.5 * np.linalg.norm(nrm, axis=1).sum(), (16 + 8) * 1.0)  # perimeter x height
+    cen = tri.mean(axis=1)
+    # outer wall normals point away from the square's centre, the hole's walls towards it (away from the solid)
+    out = np.einsum("ij,ij->i", nrm[:8, :2], cen[:8, :2] - 2.0)
+    inn = np.einsum("ij,ij->i", nrm[8:, :2], cen[8:, :2] - 2.0)
+    assert (out > 0).all() and (inn < 0).all()
