@@ -30,6 +30,13 @@ struct orc_ctx {
 /* thread-local work counters, folded into ctx->cnt by the entry points */
 static _Thread_local orc_counters tl_cnt;
 
+/* optional trace of the descents (studies only, tools/experiments/wave_model.py): per gradientDescent call one 32-byte
+ * record -- [0] passes (<= 31 recorded), [k] the accepted ladder index of pass k (1 .. 29; 0: none accepted) */
+static unsigned char *g_gd_trace = NULL;
+static size_t g_gd_trace_cap = 0, g_gd_trace_n = 0;
+void orc_set_gd_trace(unsigned char *buf, size_t cap_records) { g_gd_trace = buf; g_gd_trace_cap = cap_records; g_gd_trace_n = 0; }
+size_t orc_gd_trace_count(void) { return g_gd_trace_n; }
+
 static inline double dmax(double a, double b) { return (a < b) ? b : a; } /* std::max */
 static inline double dmin(double a, double b) { return (b < a) ? b : a; } /* std::min */
 static inline double clipd(double v, double lo, double hi) { return dmax(dmin(v, hi), lo); }
@@ -664,6 +671,7 @@ static void gradient_descent(const orc_ctx *ctx, double t_min, double t_max, con
   double x_candidate, fx_candidate;
   g = 100.0;
   int passes = 0;
+  unsigned char rec[32] = {0};
   while (iter < max_iter && !stop && fabs(*x - prev_x) > tol) {
     passes++;
     if (iter == 0) *fx = sdf_at_time(ctx, px, py, *x);
@@ -682,10 +690,22 @@ static void gradient_descent(const orc_ctx *ctx, double t_min, double t_max, con
       if ((fx_candidate - *fx) < 0) {
         *x = x_candidate;
         *fx = fx_candidate;
+        if (passes < 32) rec[passes] = (unsigned char)div;
         break;
       }
       tau = 0.5 * tau;
       if (div == 29) stop = 1;
+    }
+  }
+  if (g_gd_trace) {
+    size_t slot;
+#ifdef _OPENMP
+#pragma omp atomic capture
+#endif
+    slot = g_gd_trace_n++;
+    if (slot < g_gd_trace_cap) {
+      rec[0] = (unsigned char)(passes < 31 ? passes : 31);
+      memcpy(g_gd_trace + 32 * slot, rec, 32);
     }
   }
   tl_cnt.gd_passes += passes;

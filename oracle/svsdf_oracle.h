@@ -138,6 +138,9 @@ void orc_penalty(orc_ctx *ctx, const double *xyz, size_t P, int nthreads, int su
                  double *sdf, double *tstar, double *pcost);
 
 void orc_get_counters(const orc_ctx *ctx, orc_counters *out);
+/* studies only: trace of every gradientDescent call (32 bytes each: passes, then the accepted ladder index per pass) */
+void orc_set_gd_trace(unsigned char *buf, size_t cap_records);
+size_t orc_gd_trace_count(void);
 /* Diagnostic "device arithmetic" mode: evaluate the path's run-time sin/cos/atan2 with the ROCm device library's
  * algorithms instead of libm, and the local time of piece i as t - (T_0 + ... + T_{i-1}) instead of i successive
  * subtractions (see svsdf_oracle.c) -- the two places where the HIP kernels' arithmetic is not the reference's
