@@ -67,6 +67,9 @@ def build(force=False, verbose=False, out=OUT, extra_flags=(), tag=""):
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link, cwd=HERE)
+    if tag:   # variant builds: the objects (30 MB a set) would travel to the GPU box with every gpurun snapshot
+        for obj in objs:
+            os.remove(obj)
     return out
 
 
