@@ -743,9 +743,9 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
     // The candidates of a ladder do not depend on each other, so any number of them may be evaluated at once, by any
     // lane: the 64 lanes of the wave are dealt out evenly to the groups whose ladder is still open (16 groups: 4 lanes
     // each as before; 5 groups: 12 each; one group: its 29 candidates in one step).  Groups of a wave need different
-    // numbers of passes and of ladder steps (site counters, tools/site_stats.py: 46 % of the lanes evaluate at this site
-    // with fixed 4-lane ladders, 85 % so); a group that is done hands its lanes to the others instead of idling.  Same
-    // accepted candidate, bit for bit.
+    // numbers of passes and of ladder steps (site counters, tools/site_stats.py: with fixed 4-lane ladders 46 % of the
+    // lanes evaluate at this site, with shared ones 85 %); a group that is done hands its lanes to the others instead of
+    // idling.  Same accepted candidate, bit for bit.
     // The groups' descent state lives in the wave's LDS rows (one wave reads and writes them in program order: no
     // barrier): a serving lane reads the state of the group it works for and, if its candidate is the first accepted
     // one, writes the new (x, fx) back; the owner picks them up at the top of its next pass.  All open ladders of a
