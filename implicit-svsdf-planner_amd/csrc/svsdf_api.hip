@@ -2051,21 +2051,19 @@ int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const doubl
   return SVSDF_OK;
 }
 
-int svsdf_outline_extrude(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1, double *V_out,
-                          size_t capacity_verts, size_t *n_verts, int *F_out, size_t capacity_tris, size_t *n_tris) {
+int svsdf_outline_extrude(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1, int caps,
+                          double *V_out, size_t capacity_verts, size_t *n_verts, int *F_out, size_t capacity_tris,
+                          size_t *n_tris) {
   if (!xy || !loop_sizes || !n_verts || !n_tris || !std::isfinite(z0) || !std::isfinite(z1)) return SVSDF_ERR_INVALID;
-  size_t total = 0;
-  for (size_t l = 0; l < n_loops; ++l) {
+  for (size_t l = 0; l < n_loops; ++l)
     if (loop_sizes[l] < 3) return SVSDF_ERR_INVALID;
-    total += (size_t)loop_sizes[l];
-  }
-  *n_verts = 2 * total;
-  *n_tris = 2 * total;
-  if (!V_out || !F_out) return SVSDF_OK;
-  if (capacity_verts < 2 * total || capacity_tris < 2 * total) return SVSDF_ERR_INVALID;
   std::vector<double> V;
   std::vector<int> F;
-  svsdf_host::extrude_outline(xy, loop_sizes, n_loops, z0, z1, V, F);
+  svsdf_host::extrude_outline(xy, loop_sizes, n_loops, z0, z1, caps != 0, V, F);
+  *n_verts = V.size() / 3;
+  *n_tris = F.size() / 3;
+  if (!V_out || !F_out) return SVSDF_OK;
+  if (capacity_verts < V.size() / 3 || capacity_tris < F.size() / 3) return SVSDF_ERR_INVALID;
   std::copy(V.begin(), V.end(), V_out);
   std::copy(F.begin(), F.end(), F_out);
   return SVSDF_OK;

@@ -22,6 +22,7 @@
 // the reference's calculateSwept marches the same function through its scalarFunc, SWM:1426-1446): what is drawn is
 // the zero set of exactly the quantity whose sign decides interior / exterior for the optimizer's penalty (SWM:921).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -212,31 +213,6 @@ inline int swept_contour(ContourGrid g, const FieldEval &f, double slack, std::v
   return 0;
 }
 
-// Side surface of the extrusion of closed polylines over z in [z0, z1] (what the reference's marching-cubes mesh of an
-// extruded slab's sweep shows, SWM:321-336 / vis->visMesh): per loop of n vertices 2n mesh vertices (bottom ring, then top
-// ring) and 2n triangles, normals away from the inside (the loops have the inside on their left).  V: 3 doubles per
-// vertex, F: 3 zero-based indices per triangle.
-inline void extrude_outline(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1,
-                            std::vector<double> &V, std::vector<int> &F) {
-  V.clear();
-  F.clear();
-  size_t off = 0;
-  for (size_t l = 0; l < n_loops; ++l) {
-    const int n = loop_sizes[l];
-    const int base = (int)(V.size() / 3);
-    for (int ring = 0; ring < 2; ++ring)
-      for (int k = 0; k < n; ++k) {
-        V.push_back(xy[2 * (off + k)]); V.push_back(xy[2 * (off + k) + 1]); V.push_back(ring ? z1 : z0);
-      }
-    for (int k = 0; k < n; ++k) {
-      const int a0 = base + k, b0 = base + (k + 1) % n, a1 = a0 + n, b1 = b0 + n;
-      F.push_back(a0); F.push_back(b0); F.push_back(b1);
-      F.push_back(a0); F.push_back(b1); F.push_back(a1);
-    }
-    off += (size_t)n;
-  }
-}
-
 // signed area of a closed polyline (> 0: counter-clockwise)
 inline double polyline_area(const double *xy, int n) {
   double a = 0.0;
@@ -245,6 +221,193 @@ inline double polyline_area(const double *xy, int n) {
     a += xy[2 * k] * xy[2 * m + 1] - xy[2 * m] * xy[2 * k + 1];
   }
   return 0.5 * a;
+}
+
+namespace contour_detail {
+inline double cross2(const double *o, const double *a, const double *b) {
+  return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);
+}
+inline bool point_in_loop(const double *xy, int n, double px, double py) {   // even-odd
+  bool in = false;
+  for (int k = 0, j = n - 1; k < n; j = k++) {
+    const double xi = xy[2 * k], yi = xy[2 * k + 1], xj = xy[2 * j], yj = xy[2 * j + 1];
+    if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
+  }
+  return in;
+}
+inline bool in_triangle(const double *a, const double *b, const double *c, const double *p) {   // closed triangle, ccw
+  return cross2(a, b, p) >= 0.0 && cross2(b, c, p) >= 0.0 && cross2(c, a, p) >= 0.0;
+}
+
+// Triangulation of one counter-clockwise loop with its clockwise holes (vertex ids into P, 2 doubles per vertex): the
+// holes are joined to the outer loop by bridge edges (hole by hole from the right: the hole's right-most vertex sees
+// the outer vertex chosen as in Eberly, "Triangulation by ear clipping"), then ears are clipped.  Output triangles are
+// counter-clockwise.  Every triangle uses input vertices only, so caps and walls share their edges.
+inline void triangulate(const double *P, std::vector<int> outer, std::vector<std::vector<int>> holes, std::vector<int> &tri) {
+  auto pt = [&](int id) { return P + 2 * (size_t)id; };
+  std::vector<std::pair<double, size_t>> order;
+  for (size_t h = 0; h < holes.size(); ++h) {
+    double mx = -1e300;
+    for (int id : holes[h]) mx = std::max(mx, pt(id)[0]);
+    order.push_back({-mx, h});
+  }
+  std::sort(order.begin(), order.end());
+  for (const auto &oh : order) {
+    std::vector<int> &H = holes[oh.second];
+    size_t mi = 0;
+    for (size_t k = 1; k < H.size(); ++k)
+      if (pt(H[k])[0] > pt(H[mi])[0]) mi = k;
+    const double *M = pt(H[mi]);
+    // nearest crossing of the ray M + (t, 0), t > 0, with the outer polygon
+    double best_x = 1e300;
+    long long be = -1;
+    const size_t n = outer.size();
+    for (size_t k = 0; k < n; ++k) {
+      const double *a = pt(outer[k]), *b = pt(outer[(k + 1) % n]);
+      if ((a[1] > M[1]) == (b[1] > M[1])) continue;
+      const double x = a[0] + (M[1] - a[1]) * (b[0] - a[0]) / (b[1] - a[1]);
+      if (x >= M[0] && x < best_x) { best_x = x; be = (long long)k; }
+    }
+    if (be < 0) continue;   // not inside this loop (numerically): leave the hole out
+    size_t pi = (pt(outer[be])[0] > pt(outer[(be + 1) % n])[0]) ? (size_t)be : (size_t)((be + 1) % n);
+    const double I[2] = {best_x, M[1]};
+    // a reflex outer vertex inside triangle (M, I, P) hides P: take the one closest in angle to the ray
+    {
+      const double *Pp = pt(outer[pi]);
+      const double *ta = M, *tb = (Pp[1] < M[1]) ? Pp : I, *tc = (Pp[1] < M[1]) ? I : Pp;   // counter-clockwise
+      double best_t = 1e300, best_d = 1e300;
+      size_t cand = pi;
+      for (size_t k = 0; k < n; ++k) {
+        const double *v = pt(outer[k]);
+        if (k == pi || !(v[0] > M[0])) continue;
+        if (!in_triangle(ta, tb, tc, v)) continue;
+        const double *pv = pt(outer[(k + n - 1) % n]), *nv = pt(outer[(k + 1) % n]);
+        if (cross2(pv, v, nv) > 0.0) continue;   // convex vertices cannot hide anything
+        const double dx = v[0] - M[0], dy = std::fabs(v[1] - M[1]);
+        const double t = dy / dx, d = dx * dx + dy * dy;
+        if (t < best_t || (t == best_t && d < best_d)) { best_t = t; best_d = d; cand = k; }
+      }
+      pi = cand;
+    }
+    std::vector<int> merged;
+    merged.reserve(outer.size() + H.size() + 2);
+    for (size_t k = 0; k <= pi; ++k) merged.push_back(outer[k]);
+    for (size_t k = 0; k <= H.size(); ++k) merged.push_back(H[(mi + k) % H.size()]);
+    for (size_t k = pi; k < outer.size(); ++k) merged.push_back(outer[k]);
+    outer.swap(merged);
+  }
+  // ---- ear clipping
+  const int n = (int)outer.size();
+  if (n < 3) return;
+  std::vector<int> prv(n), nxt(n);
+  for (int k = 0; k < n; ++k) { prv[k] = (k + n - 1) % n; nxt[k] = (k + 1) % n; }
+  auto is_ear = [&](int k) -> bool {
+    const double *a = pt(outer[prv[k]]), *b = pt(outer[k]), *c = pt(outer[nxt[k]]);
+    if (!(cross2(a, b, c) > 0.0)) return false;
+    for (int q = nxt[nxt[k]]; q != prv[k]; q = nxt[q]) {
+      const double *v = pt(outer[q]);
+      if ((v[0] == a[0] && v[1] == a[1]) || (v[0] == b[0] && v[1] == b[1]) || (v[0] == c[0] && v[1] == c[1])) continue;
+      const double *pv = pt(outer[prv[q]]), *nv = pt(outer[nxt[q]]);
+      if (cross2(pv, v, nv) > 0.0) continue;                 // only reflex (or flat) vertices can lie inside an ear
+      if (in_triangle(a, b, c, v)) return false;
+    }
+    return true;
+  };
+  int left = n, cur = 0, since = 0;
+  while (left > 3) {
+    bool clip = is_ear(cur);
+    if (!clip && since > left) {
+      // no ear in a whole round (collinear runs, coincident bridge vertices): clip the flattest non-reflex corner
+      int bestk = cur;
+      double bestc = 1e300;
+      for (int q = cur, c = 0; c < left; q = nxt[q], ++c) {
+        const double cr = cross2(pt(outer[prv[q]]), pt(outer[q]), pt(outer[nxt[q]]));
+        if (cr >= 0.0 && cr < bestc) { bestc = cr; bestk = q; }
+      }
+      cur = bestk;
+      clip = true;
+    }
+    if (clip) {
+      tri.push_back(outer[prv[cur]]); tri.push_back(outer[cur]); tri.push_back(outer[nxt[cur]]);
+      nxt[prv[cur]] = nxt[cur];
+      prv[nxt[cur]] = prv[cur];
+      cur = nxt[cur];
+      --left;
+      since = 0;
+    } else {
+      cur = nxt[cur];
+      ++since;
+    }
+  }
+  tri.push_back(outer[prv[cur]]); tri.push_back(outer[cur]); tri.push_back(outer[nxt[cur]]);
+}
+}  // namespace contour_detail
+
+// Surface of the extrusion of closed polylines over z in [z0, z1] (what the reference's marching-cubes mesh of an extruded
+// slab's sweep shows, SWM:321-336 / vis->visMesh): per loop of n vertices 2n mesh vertices (bottom ring, then top ring),
+// 2n wall triangles with their normals away from the inside (the loops have the inside on their left) and, with `caps`,
+// the bottom and top faces: every counter-clockwise loop triangulated together with the clockwise loops (holes) it
+// contains, on the rings' own vertices -- a closed, consistently oriented surface.  V: 3 doubles per vertex, F: 3
+// zero-based indices per triangle.
+inline void extrude_outline(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1, bool caps,
+                            std::vector<double> &V, std::vector<int> &F) {
+  V.clear();
+  F.clear();
+  std::vector<size_t> loop_off(n_loops + 1, 0);
+  std::vector<int> base(n_loops, 0);
+  for (size_t l = 0; l < n_loops; ++l) loop_off[l + 1] = loop_off[l] + (size_t)loop_sizes[l];
+  for (size_t l = 0; l < n_loops; ++l) {
+    const int n = loop_sizes[l];
+    const size_t off = loop_off[l];
+    base[l] = (int)(V.size() / 3);
+    for (int ring = 0; ring < 2; ++ring)
+      for (int k = 0; k < n; ++k) {
+        V.push_back(xy[2 * (off + k)]); V.push_back(xy[2 * (off + k) + 1]); V.push_back(ring ? z1 : z0);
+      }
+    for (int k = 0; k < n; ++k) {
+      const int a0 = base[l] + k, b0 = base[l] + (k + 1) % n, a1 = a0 + n, b1 = b0 + n;
+      F.push_back(a0); F.push_back(b0); F.push_back(b1);
+      F.push_back(a0); F.push_back(b1); F.push_back(a1);
+    }
+  }
+  if (!caps) return;
+  // holes go to the smallest counter-clockwise loop that contains them
+  std::vector<double> area(n_loops);
+  for (size_t l = 0; l < n_loops; ++l) area[l] = polyline_area(xy + 2 * loop_off[l], loop_sizes[l]);
+  std::vector<std::vector<size_t>> holes_of(n_loops);
+  for (size_t h = 0; h < n_loops; ++h) {
+    if (area[h] >= 0.0) continue;
+    long long best = -1;
+    for (size_t o = 0; o < n_loops; ++o) {
+      if (area[o] <= 0.0 || area[o] < -area[h]) continue;
+      if (!contour_detail::point_in_loop(xy + 2 * loop_off[o], loop_sizes[o], xy[2 * loop_off[h]], xy[2 * loop_off[h] + 1])) continue;
+      if (best < 0 || area[o] < area[(size_t)best]) best = (long long)o;
+    }
+    if (best >= 0) holes_of[(size_t)best].push_back(h);
+  }
+  for (size_t o = 0; o < n_loops; ++o) {
+    if (area[o] <= 0.0) continue;
+    std::vector<int> outer(loop_sizes[o]);
+    for (int k = 0; k < loop_sizes[o]; ++k) outer[k] = (int)(loop_off[o] + (size_t)k);
+    std::vector<std::vector<int>> holes;
+    for (size_t h : holes_of[o]) {
+      std::vector<int> H(loop_sizes[h]);
+      for (int k = 0; k < loop_sizes[h]; ++k) H[k] = (int)(loop_off[h] + (size_t)k);
+      holes.push_back(H);
+    }
+    std::vector<int> tri;   // ids into xy (outline vertex numbering)
+    contour_detail::triangulate(xy, outer, holes, tri);
+    auto mesh_id = [&](int id, bool top) -> int {
+      size_t l = 0;
+      while (l + 1 < n_loops && (size_t)id >= loop_off[l + 1]) ++l;
+      return base[l] + (int)((size_t)id - loop_off[l]) + (top ? loop_sizes[l] : 0);
+    };
+    for (size_t t = 0; t + 2 < tri.size(); t += 3) {
+      // top face: counter-clockwise seen from above (normal +z); bottom face: reversed (normal -z)
+      F.push_back(mesh_id(tri[t], true)); F.push_back(mesh_id(tri[t + 1], true)); F.push_back(mesh_id(tri[t + 2], true));
+      F.push_back(mesh_id(tri[t], false)); F.push_back(mesh_id(tri[t + 2], false)); F.push_back(mesh_id(tri[t + 1], false));
+    }
+  }
 }
 
 }  // namespace svsdf_host

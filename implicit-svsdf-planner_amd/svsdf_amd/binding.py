@@ -217,22 +217,23 @@ def mesh_outline_obj(path, z0=0.0):
     return xy, loops.value
 
 
-def outline_extrude(loops, z0=-0.5, z1=0.5):
-    """Side surface of the extrusion of closed polylines (svsdf_outline_extrude): V (nv, 3), F (nf, 3).  Host only."""
+def outline_extrude(loops, z0=-0.5, z1=0.5, caps=True):
+    """Surface of the extrusion of closed polylines (svsdf_outline_extrude): V (nv, 3), F (nf, 3); walls and, with caps,
+    the bottom and top faces (a closed surface).  Host only."""
     xy = _f64(np.vstack(loops))
     sizes = np.ascontiguousarray([len(lp) for lp in loops], dtype=np.int32)
     nv, nf = C.c_size_t(), C.c_size_t()
     L = lib()
-    L.svsdf_outline_extrude.argtypes = [_dp, _ip, C.c_size_t, C.c_double, C.c_double, _dp, C.c_size_t,
+    L.svsdf_outline_extrude.argtypes = [_dp, _ip, C.c_size_t, C.c_double, C.c_double, C.c_int, _dp, C.c_size_t,
                                         C.POINTER(C.c_size_t), _ip, C.c_size_t, C.POINTER(C.c_size_t)]
-    rc = L.svsdf_outline_extrude(_p(xy), sizes.ctypes.data_as(_ip), len(sizes), z0, z1, None, 0, C.byref(nv), None, 0,
-                                 C.byref(nf))
+    rc = L.svsdf_outline_extrude(_p(xy), sizes.ctypes.data_as(_ip), len(sizes), z0, z1, int(bool(caps)), None, 0,
+                                 C.byref(nv), None, 0, C.byref(nf))
     if rc:
         raise SvsdfError(f"svsdf_outline_extrude failed: {rc}")
     V = np.zeros((nv.value, 3))
     F = np.zeros((nf.value, 3), dtype=np.int32)
-    L.svsdf_outline_extrude(_p(xy), sizes.ctypes.data_as(_ip), len(sizes), z0, z1, _p(V), nv.value, C.byref(nv),
-                            F.ctypes.data_as(_ip), nf.value, C.byref(nf))
+    L.svsdf_outline_extrude(_p(xy), sizes.ctypes.data_as(_ip), len(sizes), z0, z1, int(bool(caps)), _p(V), nv.value,
+                            C.byref(nv), F.ctypes.data_as(_ip), nf.value, C.byref(nf))
     return V, F
 
 

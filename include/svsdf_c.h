@@ -316,12 +316,15 @@ int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const doubl
                         double *xy_out, size_t capacity_verts, size_t *n_verts, int *loop_sizes, size_t capacity_loops,
                         size_t *n_loops, svsdf_outline_stats *stats);
 
-/* The mesh vis->visMesh("sweptmesh2D", ...) is given (SWM:331): the side surface of the outline's extrusion over
- * z in [z0, z1] -- per loop of n vertices 2n mesh vertices (bottom ring, top ring) and 2n triangles with their normals
- * away from the inside.  V_out: 3 doubles per vertex, F_out: 3 zero-based indices per triangle; both may be NULL to
- * query the counts.  Host only (no GPU). */
-int svsdf_outline_extrude(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1, double *V_out,
-                          size_t capacity_verts, size_t *n_verts, int *F_out, size_t capacity_tris, size_t *n_tris);
+/* The mesh vis->visMesh("sweptmesh2D", ...) is given (SWM:331): the surface of the outline's extrusion over z in
+ * [z0, z1] -- per loop of n vertices 2n mesh vertices (bottom ring, top ring) and 2n wall triangles with their normals
+ * away from the inside; with caps != 0 also the bottom and top faces (every counter-clockwise loop triangulated with
+ * the holes it contains, on the rings' own vertices): a closed, consistently oriented triangle surface like the
+ * reference's marching-cubes output.  V_out: 3 doubles per vertex, F_out: 3 zero-based indices per triangle; both may
+ * be NULL to query the counts.  Host only (no GPU). */
+int svsdf_outline_extrude(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1, int caps,
+                          double *V_out, size_t capacity_verts, size_t *n_verts, int *F_out, size_t capacity_tris,
+                          size_t *n_tris);
 
 /* ---- host-side MINCO helpers (MNC:397-655) ------------------------------------------------------- */
 /* waypoints inPs: 3 x (N-1) col-major; out coeffs (6N) x 3 col-major. */

@@ -127,8 +127,8 @@ class TrajOptimizerHip {
 
   // SweptVolumeManager::calculateSwept(U_, G_) (sw_manager.hpp:321-336 -> sw_calculate.cpp:4-305; unused in the release,
   // shown with vis->visMesh): vertices U (3 per row) and triangles G (3 zero-based indices per row) of the swept volume's
-  // side surface for the trajectory (T[N], coeffs (6N) x 3 column-major) -- the outline of its z = 0 section
-  // (svsdf_swept_outline, cell size `cell`) extruded over [zmin, zmax] (the shipped meshes are slabs |z| <= 0.5).
+  // closed surface for the trajectory (T[N], coeffs (6N) x 3 column-major) -- the outline of its z = 0 section
+  // (svsdf_swept_outline, cell size `cell`) extruded over [zmin, zmax] (the shipped meshes are slabs |z| <= 0.5), walls + caps.
   // outline_xy / loop_sizes (may be null) receive the closed polylines themselves.  Returns 0 or an SVSDF_ERR_* code.
   int calculateSwept(const double *T, const double *coeffs, int N, std::vector<double> &U, std::vector<int> &G,
                      double cell = 0.05, double zmin = -0.5, double zmax = 0.5, std::vector<double> *outline_xy = nullptr,
@@ -145,11 +145,11 @@ class TrajOptimizerHip {
       if (rc) return rc;
     }
     std::size_t mv = 0, mf = 0;
-    rc = svsdf_outline_extrude(xy.data(), sizes.data(), nl, zmin, zmax, nullptr, 0, &mv, nullptr, 0, &mf);
+    rc = svsdf_outline_extrude(xy.data(), sizes.data(), nl, zmin, zmax, 1, nullptr, 0, &mv, nullptr, 0, &mf);
     if (rc) return rc;
     U.assign(3 * mv, 0.0);
     G.assign(3 * mf, 0);
-    if (mv) rc = svsdf_outline_extrude(xy.data(), sizes.data(), nl, zmin, zmax, U.data(), mv, &mv, G.data(), mf, &mf);
+    if (mv) rc = svsdf_outline_extrude(xy.data(), sizes.data(), nl, zmin, zmax, 1, U.data(), mv, &mv, G.data(), mf, &mf);
     if (outline_xy) *outline_xy = xy;
     if (loop_sizes) *loop_sizes = sizes;
     return rc;

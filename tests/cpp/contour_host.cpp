@@ -1,10 +1,12 @@
 // contour_host.cpp -- host harness for csrc/svsdf_contour.hpp (tests/test_contour.py): zero contours of analytic fields.
 // usage: contour_host <field> <h> <levels>     field: disc | two | ring | saddle | steep
-// prints: nodes_evaluated dense_nodes open_chains nloops, then per loop "size signed_area", then a checksum of all vertices
+// prints: nodes_evaluated dense_nodes open_chains nloops, then per loop "size signed_area", a checksum of all vertices,
+// then the closed-surface check of the extrusion: bad edges (0) and the enclosed volume
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -53,5 +55,23 @@ int main(int argc, char **argv) {
     maxres = std::fmax(maxres, std::fabs(field(name, xy[2 * k], xy[2 * k + 1])));
   }
   std::printf("%.12f %.12f %.6e\n", sx, sy, maxres);
+  // closed surface of the extrusion (walls + caps): every directed edge once, its reverse once; volume = area x height
+  std::vector<double> V;
+  std::vector<int> F;
+  svsdf_host::extrude_outline(xy.data(), loops.data(), loops.size(), -0.5, 0.5, true, V, F);
+  std::map<std::pair<int, int>, int> edges;
+  double vol = 0.0;
+  for (size_t t = 0; t + 2 < F.size(); t += 3) {
+    const int id[3] = {F[t], F[t + 1], F[t + 2]};
+    for (int k = 0; k < 3; ++k) edges[{id[k], id[(k + 1) % 3]}]++;
+    const double *a = &V[3 * (size_t)id[0]], *b = &V[3 * (size_t)id[1]], *c = &V[3 * (size_t)id[2]];
+    vol += a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+  }
+  int bad = 0;
+  for (const auto &e : edges) {
+    if (e.second != 1) ++bad;
+    if (!edges.count({e.first.second, e.first.first})) ++bad;
+  }
+  std::printf("%d %.12f\n", bad, vol / 6.0);
   return 0;
 }

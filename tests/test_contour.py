@@ -21,7 +21,9 @@ def _run(exe, field, h, levels):
     nodes, dense, open_chains, nloops = (int(v) for v in out[0].split())
     loops = [(int(a), float(b)) for a, b in (line.split() for line in out[1:1 + nloops])]
     sx, sy, maxres = (float(v) for v in out[1 + nloops].split())
-    return dict(nodes=nodes, dense=dense, open=open_chains, loops=loops, sx=sx, sy=sy, maxres=maxres)
+    bad, vol = out[2 + nloops].split()
+    return dict(nodes=nodes, dense=dense, open=open_chains, loops=loops, sx=sx, sy=sy, maxres=maxres,
+                bad_edges=int(bad), volume=float(vol))
 
 
 def test_disc_area_orientation_and_convergence(harness):
@@ -56,18 +58,36 @@ def test_band_gives_the_dense_result_with_a_fraction_of_the_nodes(harness, field
     assert dense["nodes"] == dense["dense"]
     assert band["nodes"] < 0.15 * dense["nodes"]
     assert band["open"] == 0 and dense["open"] == 0      # "steep" is not 1-Lipschitz and jumps: the band alone would miss cells
+    # the extrusion of marching-squares loops (runs of collinear vertices, holes) closes: walls + caps, volume = area x 1
+    assert band["bad_edges"] == 0
+    assert band["volume"] == pytest.approx(sum(a for _, a in band["loops"]), rel=1e-9)
     # same cells marched where the zero set is -> the very same vertices (crossing points depend on two node values only)
     assert sorted(band["loops"]) == sorted(dense["loops"])
     assert band["sx"] == pytest.approx(dense["sx"], abs=1e-9) and band["sy"] == pytest.approx(dense["sy"], abs=1e-9)
 
 
-def test_outline_extrusion_is_a_wall_with_outward_normals(built):
+def _closed_surface_checks(V, F, area, height):
+    import numpy as np
+    # every directed edge has its reverse exactly once: closed, consistently oriented 2-manifold
+    edges = {}
+    for t in F:
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            edges[(int(a), int(b))] = edges.get((int(a), int(b)), 0) + 1
+    assert all(c == 1 for c in edges.values())
+    assert all((b, a) in edges for (a, b) in edges)
+    # volume by the divergence theorem = area x height, outward orientation
+    tri = V[F]
+    vol = np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2])).sum() / 6.0
+    assert vol == __import__("pytest").approx(area * height, rel=1e-9)
+
+
+def test_outline_extrusion_walls_and_caps(built):
     """svsdf_outline_extrude (host only): a counter-clockwise square with a clockwise square hole."""
     import numpy as np
     import svsdf_amd
     outer = np.array([[0, 0], [4, 0], [4, 4], [0, 4]], dtype=float)            # inside on the left
     hole = np.array([[1, 1], [1, 3], [3, 3], [3, 1]], dtype=float)             # clockwise
-    V, F = svsdf_amd.outline_extrude([outer, hole], z0=-0.5, z1=0.5)
+    V, F = svsdf_amd.outline_extrude([outer, hole], z0=-0.5, z1=0.5, caps=False)
     assert V.shape == (16, 3) and F.shape == (16, 3)
     assert set(np.unique(V[:, 2])) == {-0.5, 0.5}
     tri = V[F]
@@ -79,3 +99,26 @@ def test_outline_extrusion_is_a_wall_with_outward_normals(built):
     out = np.einsum("ij,ij->i", nrm[:8, :2], cen[:8, :2] - 2.0)
     inn = np.einsum("ij,ij->i", nrm[8:, :2], cen[8:, :2] - 2.0)
     assert (out > 0).all() and (inn < 0).all()
+    V, F = svsdf_amd.outline_extrude([outer, hole], z0=-0.5, z1=0.5, caps=True)
+    assert V.shape == (16, 3) and len(F) == 16 + 2 * 8                         # 8 + 2 bridge vertices - 2 cap triangles, twice
+    _closed_surface_checks(V, F, 16.0 - 4.0, 1.0)
+
+
+def test_caps_on_curved_loops_holes_and_reference_outlines(built):
+    """Closed surface on loops with many collinear / nearly collinear vertices: a disc with two holes, two separate
+    components, and the z = 0 outlines of the reference's meshes (star: concave, sdArc: 754 vertices)."""
+    import numpy as np
+    import svsdf_amd
+    from svsdf_amd import workload
+    th = np.linspace(0.0, 2.0 * np.pi, 181)[:-1]
+    circ = lambda cx, cy, r, sgn: np.c_[cx + r * np.cos(sgn * th), cy + r * np.sin(sgn * th)]
+    area = lambda lp: 0.5 * np.sum(lp[:, 0] * np.roll(lp[:, 1], -1) - np.roll(lp[:, 0], -1) * lp[:, 1])
+    loops = [circ(0, 0, 3.0, +1), circ(-1.2, 0.3, 0.8, -1), circ(1.1, -0.4, 0.9, -1), circ(8.0, 1.0, 1.5, +1)]
+    V, F = svsdf_amd.outline_extrude(loops, z0=0.0, z1=2.0)
+    _closed_surface_checks(V, F, sum(area(lp) for lp in loops), 2.0)
+    for name in ("star", "sdArc", "sdHorseshoe"):
+        lp = workload.mesh_outline(name)
+        if area(lp) < 0:
+            lp = lp[::-1].copy()
+        V, F = svsdf_amd.outline_extrude([lp], z0=-0.5, z1=0.5)
+        _closed_surface_checks(V, F, area(lp), 1.0)
