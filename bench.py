@@ -257,6 +257,42 @@ class Runner:
         return 1e3 * (time.perf_counter() - t0) / steps
 
 
+def combine_ab(r, a, devices, steps):
+    """In-process multi-device context: `steps` evaluations under the host combine and under the RCCL combine, same
+    context, same resident stripes; the communicator's rank count is read back from RCCL (ncclCommCount)."""
+    out = {"steps": steps}
+    distinct = len(set(devices)) == len(devices)
+    for mode in ("host", "rccl"):
+        if mode == "rccl" and not distinct:
+            out["rccl_ms_per_step"] = None
+            out["rccl_ranks"] = 0
+            out["rccl_note"] = "--devices repeats an ordinal (several stripes on one GPU): an RCCL communicator needs one rank per distinct GPU; skipped"
+            continue
+        try:
+            r.ctx.set_combine(mode)
+        except Exception as e:      # librccl missing / init failure: say so, do not fake a number
+            out[f"{mode}_ms_per_step"] = None
+            out["rccl_note"] = f"RCCL combine unavailable: {e}"
+            continue
+        for _ in range(2):
+            r.step()
+        r.fence()
+        cm = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.step()
+            cm += r.ctx.stats()["combine_ms"]
+        r.fence()
+        out[f"{mode}_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+        out[f"{mode}_combine_only_ms"] = cm / steps
+        if mode == "rccl":
+            out["rccl_ranks"] = r.ctx.group_info()["rccl_ranks"]
+    out["note"] = ("whole-evaluation time per step under each combine (same context, same stripes); *_combine_only_ms: host time "
+                   "from 'all devices done' to 'summed partial on the host'; rccl_ranks: ncclCommCount of the communicator")
+    r.ctx.set_combine({"auto": "host", "host": "host", "rccl": "rccl"}[a.combine])
+    return out
+
+
 def allreduce_ms(tdist, n, reps=50):
     """The collective alone: RCCL all-reduce of n doubles (device buffer, in place), HIP-event timed."""
     import torch
@@ -323,6 +359,101 @@ def sub_run(a, name, P, dist_name, rank, world, local_rank, tdist, devices, step
            "full_callback_ms": r.full_callback(min(steps, 5))}
     r.opt._ctx.close()
     return out
+
+
+def quick_run(name, P, steps, local_rank, generic=False):
+    """Compact sub-measurement of another BASELINE config on one GPU: resident cloud, settle, `steps` timed evaluations
+    of the inner operator (fenced), the same way the headline is timed."""
+    import torch
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make(name, P=P, minco=svsdf_amd.minco_coeffs)
+    c = svsdf_amd.SvsdfContext(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
+                               poly_params=w["poly_params"], polygon=w["polygon"], head_state=w["head_state"],
+                               tail_state=w["tail_state"], device=local_rank)
+    t0 = time.perf_counter()
+    c.set_points(w["points"])
+    set_ms = 1e3 * (time.perf_counter() - t0)
+    n_settle = 0
+    while n_settle < 8:
+        c.eval_penalty(w["coeffs"], w["T"])
+        n_settle += 1
+        if c.stats()["plan_settled"] and n_settle >= 2:
+            break
+    c.eval_penalty(w["coeffs"], w["T"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.eval_penalty(w["coeffs"], w["T"])
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    st, pl = c.stats(), c.get_plan()
+    out = {"workload": f"{name}: {w['shape']}, {len(w['T'])} pieces, {P} corridor points", "points_total": P, "steps": steps,
+           "ms_per_step": ms, "value": P / (ms * 1e-3), "unit": "query-points/s", "set_points_ms": set_ms,
+           "settle_evaluations": n_settle, "interior_fraction": st["interior_points"] / max(st["points"], 1),
+           "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][pl["bound_mode"]], "batches": pl["batches"],
+                    "lanes_per_query": pl["lanes_per_query"], "tail_iter": st["tail_iter"]}}
+    if generic:
+        rng = np.random.default_rng(11)
+        N = len(w["T"])
+        x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+        x[:N] *= 1.0 + 1e-3 * rng.standard_normal(N)
+        T = svsdf_amd.forward_T(x[:N])
+        coeffs = svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], x[N:].reshape(-1, 3), T)
+        for _ in range(2):
+            c.eval_penalty(coeffs, T)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.eval_penalty(coeffs, T)
+        torch.cuda.synchronize()
+        out["generic_durations_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+    c.close()
+    return out
+
+
+def first_optimisation(name, P, local_rank, callbacks=30, seed=5):
+    """What optimize_traj_lmbm pays from a cold context (back_end_optimizer.cpp:29-36): svsdf_set_points, then
+    `callbacks` full callbacks (a14) whose x differ from call to call like an optimiser's iterates (relative 1e-3), the
+    plan-deciding evaluations included.  Wall time of the whole sequence and of its parts."""
+    import torch
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make(name, P=P, minco=svsdf_amd.minco_coeffs)
+    N = len(w["T"])
+    opt = svsdf_amd.TrajOptimizer()
+    opt.setParam(dict(rho=w["rho"], weight_p=w["weight_p"], safety_hor=w["safety_hor"], inputdata=f"shapes/{w['shape']}.obj",
+                      poly_params=w["poly_params"], polygon=w["polygon"], device=local_rank))
+    opt.setConditions(w["head_state"], w["tail_state"], N)
+    x0 = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+    rng = np.random.default_rng(seed)
+    xs = [x0 * (1.0 + 1e-3 * rng.standard_normal(len(x0))) for _ in range(callbacks)]
+    torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    opt.setPoints(w["points"])
+    ctx = opt._context()          # creates the context and uploads the cloud
+    t_set = time.perf_counter() - t_all
+    per = []
+    settled_at = None
+    for k, x in enumerate(xs):
+        t0 = time.perf_counter()
+        opt.costFunctionLmbmParallel(x)
+        per.append(1e3 * (time.perf_counter() - t0))
+        if settled_at is None and ctx.stats()["plan_settled"]:
+            settled_at = k + 1
+    torch.cuda.synchronize()
+    total = 1e3 * (time.perf_counter() - t_all)
+    pl = ctx.get_plan()
+    opt._ctx.close()
+    return {"workload": f"{name}, {P} points, cold context", "callbacks": callbacks, "total_ms": total,
+            "set_points_and_create_ms": 1e3 * t_set, "first_callback_ms": per[0], "second_callback_ms": per[1],
+            "mean_callback_ms": float(np.mean(per)), "steady_callback_ms": float(np.mean(per[-10:])),
+            "callbacks_until_plan_settled": settled_at,
+            "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][pl["bound_mode"]], "batches": pl["batches"],
+                     "lanes_per_query": pl["lanes_per_query"]},
+            "note": "wall time of svsdf_create + svsdf_set_points + 30 costFunctionLmbmParallel calls with x * (1 + 1e-3 N(0,1)) "
+                    "each (generic piece durations: the reference-faithful piece time runs from the first call on); the plan "
+                    "follows deterministic rules (no timing inside the library)"}
 
 
 def main():
@@ -468,6 +599,9 @@ def main():
                      "k_round_ms_serialized_per_step": r.round_ms_serial,
                      "fp64": fp64},
     }
+    if a.inprocess and multi:
+        # both ways of summing the devices' partials, timed in this run on this workload
+        res["combine_ab"] = combine_ab(r, a, devices, max(3, min(a.steps, 10)))
     if generic is not None:
         res["generic_durations"] = generic
     res["evaluations_in_this_run"] = r.n_eval   # of the headline workload (settle + warm-up + timed + profiled + callbacks)
@@ -500,6 +634,13 @@ def main():
     if not multi and not a.no_extras and a.config is None and a.points is None and a.dist == "corridor":
         res["north_star"] = sub_run(a, "NS", workload.CONFIGS["NS"]["P"], "corridor", rank, world, local_rank, None, None, a.extra_steps)
         res["map_distribution"] = sub_run(a, name, P_total, "map", rank, world, local_rank, None, None, a.extra_steps)
+    if not multi and not a.no_extras and a.config is None and a.points is None and a.dist == "corridor":
+        # every other BASELINE config at its full size on this GPU (compact objects), C4's whole 4 M cloud on ONE device
+        # (the base of the N > 1 lines, which run C4), and what one optimisation pays from a cold context
+        res["other_configs"] = {c: quick_run(c, workload.CONFIGS[c]["P"], st_, local_rank, generic=True)
+                                for c, st_ in (("C1", 20), ("C2", 20), ("C5", 5))}
+        res["c4_one_gpu"] = quick_run("C4", workload.CONFIGS["C4"]["P"], 5, local_rank)
+        res["first_optimisation"] = first_optimisation(name, P_total, local_rank)
     if not multi and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]

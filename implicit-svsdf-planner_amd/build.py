@@ -19,6 +19,9 @@ DEPS = sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(HERE, "..", "i
 OUT = os.path.join(HERE, "libsvsdf_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 NSLICES = 4
+# what a slice object depends on (svsdf_shape_slice.hip's include closure); the api object depends on everything
+SLICE_DEPS = [os.path.join(CSRC, f) for f in ("svsdf_shape_slice.hip", "svsdf_launch.hpp", "svsdf_kernels.hpp",
+                                               "svsdf_shapes.hpp", "svsdf_polygon.hpp", "svsdf_frontend.hpp")]
 
 # -ffp-contract=off: the parity build rounds every operation like the reference's x86-64 build
 # (no FMA contraction); see DESIGN.md "Floating-point policy".
@@ -49,13 +52,24 @@ def build(force=False, verbose=False, out=OUT, extra_flags=(), tag=""):
     units = [("api" + tag, os.path.join(CSRC, "svsdf_api.hip"), [])]
     units += [(f"slice{k}{tag}", os.path.join(CSRC, "svsdf_shape_slice.hip"), [f"-DSVSDF_SLICE={k}"]) for k in range(NSLICES)]
     procs = []
+    objs_kept = []
+    flags_key = " ".join(CFLAGS + list(extra_flags))
     for name, src, defs in units:
         obj = os.path.join(OBJDIR, name + ".o")
+        # incremental: an object whose sources (and flags) did not change since it was compiled is kept -- a host-side
+        # edit of svsdf_api.hip then costs one translation unit instead of five
+        deps = SLICE_DEPS if name.startswith("slice") else DEPS
+        stamp = obj + ".flags"
+        if (not force and not tag and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flags_key and
+                all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps if os.path.exists(d))):
+            objs_kept.append(obj)
+            continue
+        open(stamp, "w").write(flags_key)
         cmd = [hipcc] + CFLAGS + list(extra_flags) + defs + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, obj, subprocess.Popen(cmd, cwd=HERE)))
-    objs = []
+    objs = list(objs_kept)
     for cmd, obj, p in procs:
         if p.wait() != 0:
             for _, _, q in procs:

@@ -141,10 +141,18 @@ struct svsdf_ctx {
   int G_env = 0, G_late_env = 0;
   // batch count of a large shard in the scanning bound modes: chosen by timing real evaluations (any split gives the
   // same bits): 0 idle / done, 1 next evaluation learns the launch plan with one batch, 2.. timing candidate bt_k
-  int bt_state = 0, bt_k = 0, bt_ncand = 0, bt_cand[3] = {1, 1, 1};
-  double bt_ms[3] = {0, 0, 0};
+  int bt_state = 0, bt_k = 0, bt_rep = 0, bt_ncand = 0, bt_cand[3] = {1, 1, 1};
+  double bt_ms[3] = {0, 0, 0}, bt_samples[3] = {0, 0, 0};
   long long prev_nsolve[kMaxIter] = {};  // solves per GSIP iteration of the previous evaluation (same point set)
   bool have_prev_nsolve = false;
+  // fused GSIP tail (k_tail): all iterations from tail_iter on in one launch per batch
+  int tail_mode = -1;                    // -1: by the previous evaluation's active counts, -2: off (launch chain only), >= 0: pinned
+  long long tail_below = 16384;          // auto: the whole GSIP loop runs in k_tail when the shard has at most this many interior points
+  int tail_all_after = 1 << 30;          // steps of a point inside k_tail after which every sample is requested (-1: like the chain)
+  int tail_iter = -1;                    // this evaluation: iteration the tail starts at (-1: none)
+  long long prev_nactive[kMaxIter] = {}; // active GSIP points per iteration of the previous evaluation, up to its tail
+  int prev_tail_iter = -1;
+  bool have_prev_nactive = false;
   long long wide32_below = 2000, wide16_below = 5000, wide8_below = 40000;  // env SVSDF_WIDE32 / SVSDF_WIDE16 / SVSDF_WIDE8
   bool select_env = false, all_iter_env = false;
   double select_delta = 0.1;  // k_round: solve the samples whose upper bound is within this of the best one first
@@ -176,6 +184,7 @@ struct svsdf_ctx {
   size_t ev_used = 0;
   std::vector<std::pair<size_t, size_t>> refine_events;  // k_solve launches: (start, stop) indices into ev_pool
   std::vector<std::pair<size_t, size_t>> round_events;   // k_round launches
+  std::vector<std::pair<size_t, size_t>> tail_events;    // k_tail launches
   svsdf_stats stats{};
 
   // in-process multi-GPU group (svsdf_config::n_devices > 1): this context then owns no device state of its
@@ -200,7 +209,7 @@ struct svsdf_ctx {
 namespace {
 
 constexpr size_t kOutPartial = 19 * kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 11 + kMaxIter;   // partial | 9 counters | solves per iteration | round scans | speculative
+constexpr size_t kOutDoubles = kOutPartial + 11 + 2 * kMaxIter;   // partial | 9 counters | solves per iteration | round scans | speculative | active per iteration
 
 int fail(svsdf_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -276,6 +285,10 @@ bool launch_k_round(int shape, int lp, int mode, unsigned grid, size_t lds, hipS
 bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a) {
   shape = compiled_shape(shape);
   SVSDF_SLICE_DISPATCH(launch_k_classify, grid, lds, st, a)
+}
+bool launch_k_tail(int shape, int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunch &a) {
+  shape = compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_tail, mode, grid, lds, st, a)
 }
 bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out) {
   shape = compiled_shape(shape);
@@ -356,6 +369,52 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
     (void)hipEventRecord(ctx->ev_pool[e1], st);
     ctx->round_events.emplace_back(e0, e1);
   }
+}
+
+// k_tail: every GSIP iteration of batch b from `it0` on, in one launch (two points per wave, solved in the wave).
+void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
+  const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
+  const bool scans = mode != 0;
+  const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
+  const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
+  const int all_after = (ctx->tail_all_after < 0) ? std::max(0, all_it - it0) : ctx->tail_all_after;
+  // the active count lives on the device; the grid is sized by what the previous evaluation had there (surplus blocks
+  // exit at once, missing ones are made up for by the waves' work fetch)
+  long long pts = std::max(1, ctx->bcount[b]);
+  if (ctx->have_prev_nactive && it0 <= ctx->prev_tail_iter && it0 < kMaxIter)
+    pts = std::min<long long>(pts, ctx->prev_nactive[it0] / std::max(1, ctx->nbatch) * 5 / 4 + 64);
+  const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (ctx->poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
+  const size_t lds = lds_tables + (kTailBlock / 64) * kTailWaveLds;
+  const long long per_block = (kTailBlock / 64) * 2;
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((pts + per_block - 1) / per_block, (long long)ctx->n_cu * 3));
+  const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
+  const TailLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->P, it0, mode,
+                     sel, ctx->select_delta, all_after, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
+                     ctx->d_ctl + b, ctx->round_list, ctx->prune};
+  size_t e0 = 0, e1 = 0;
+  if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
+  (void)launch_k_tail(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a);
+  if (ctx->profile) {
+    e1 = next_event(ctx);
+    (void)hipEventRecord(ctx->ev_pool[e1], st);
+    ctx->tail_events.emplace_back(e0, e1);
+  }
+  ctx->stats.tail_launches++;
+}
+
+// Iteration the fused tail starts at in this evaluation.  Measured (round 4, profiles/r04_tail_*): the launch chain packs the
+// solves of all points 32 to a wave and runs k_round at 4 waves per SIMD -- wherever a launch still holds more points than
+// the chip keeps in flight at two per wave it has several times the tail's throughput, and its last launches take 5 - 50 us
+// each, so at 100 k - 1 M points the tail only costs time (C2 + 6 %, C3 + 2 %, NS + 3 % with the threshold at 4096 points).
+// A small cloud is a pure latency chain of ~ 20 launches: there the whole GSIP loop runs in the tail (it0 = 0; C1, 10 k
+// points: 0.90 -> 0.76 ms).  Rule: every GSIP iteration in k_tail when the previous evaluation of this point set had at
+// most tail_below interior points, the launch chain otherwise; SVSDF_TAIL pins an iteration or turns the tail off.  Any
+// choice gives the same bits.
+int choose_tail_iter(const svsdf_ctx *ctx) {
+  if (ctx->tail_mode == -2) return -1;
+  if (ctx->tail_mode >= 0) return std::min(ctx->tail_mode, (int)kMaxIter - 2);
+  if (!ctx->have_prev_nactive) return -1;   // first evaluation of a point set: the interior count is not known yet
+  return (ctx->prev_nactive[0] <= ctx->tail_below) ? 0 : -1;
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
@@ -500,7 +559,7 @@ int join_batches(svsdf_ctx *ctx) {
 //   R_i = k_round(i): close the rounds whose samples S_(i-1) solved, open the next ones, select
 //   S_i = k_solve over the samples R_i selected.
 // enqueue_solve_round(i) enqueues S_i then R_(i+1).
-void enqueue_solve_round(svsdf_ctx *ctx, int it) {
+void enqueue_solve_round(svsdf_ctx *ctx, int it, bool tail_next = false) {
   for (int b = 0; b < ctx->nbatch; ++b) {
     hipStream_t st = ctx->bstream[b];
     BatchCtl *ctl = ctx->d_ctl + b;
@@ -521,7 +580,8 @@ void enqueue_solve_round(svsdf_ctx *ctx, int it) {
       else if (n < ctx->wide8_below) G = std::max(G, 8);
     }
     launch_solve(ctx, G, st, q, (long long)ctx->bcount[b] * kMaxSlots, ctx->gs.sq_sdf, ctx->gs.sq_t, ctl, it + 1);
-    launch_round(ctx, st, b, it + 1);
+    if (tail_next) launch_tail(ctx, st, b, it + 1);
+    else launch_round(ctx, st, b, it + 1);
   }
 }
 
@@ -534,6 +594,7 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
   ctx->ev_used = 0;
   ctx->refine_events.clear();
   ctx->round_events.clear();
+  ctx->tail_events.clear();
   ctx->stats = svsdf_stats{};
   ctx->stats.points = ctx->P;
   const size_t e_begin = next_event(ctx);
@@ -542,6 +603,7 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), ctx->stream));
   HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
+  const int m = ctx->tail_iter = choose_tail_iter(ctx);
   for (int b = 0; b < ctx->nbatch; ++b) {
     hipStream_t st = ctx->bstream[b];
     BatchCtl *ctl = ctx->d_ctl + b;
@@ -552,10 +614,17 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
     const double cull_thresh = (allow_cull && ctx->cull && ctx->cull_ok) ? ctx->cfg.safety_hor + 1e-9 : std::numeric_limits<double>::infinity();
     launch_solve(ctx, ctx->G, st, qm, ctx->bcount[b], ctx->d_sdf, ctx->d_t, ctl, 0, cull_thresh);
     launch_classify(ctx, st, b);
-    launch_round(ctx, st, b, 0);
+    if (m == 0) launch_tail(ctx, st, b, 0);
+    else launch_round(ctx, st, b, 0);
   }
-  for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
-  ctx->it_done = ctx->first_iters;
+  if (m >= 0) {
+    // launch chain up to iteration m, everything after it in k_tail: nothing is ever left pending
+    for (int it = 0; it < m; ++it) enqueue_solve_round(ctx, it, it == m - 1);
+    ctx->it_done = kMaxIter + 1;   // (an index whose pending-solve count is always zero)
+  } else {
+    for (int it = 0; it < ctx->first_iters; ++it) enqueue_solve_round(ctx, it);
+    ctx->it_done = ctx->first_iters;
+  }
   return join_batches(ctx);
 }
 
@@ -570,6 +639,7 @@ int swept_field(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, do
   ctx->ev_used = 0;
   ctx->refine_events.clear();
   ctx->round_events.clear();
+  ctx->tail_events.clear();
   ctx->stats = svsdf_stats{};
   ctx->stats.points = ctx->P;
   int rc = upload_traj(ctx, N, coeffs, T);
@@ -648,9 +718,14 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.batches = ctx->nbatch;
   for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
   ctx->have_prev_nsolve = true;
+  for (int i = 0; i < kMaxIter; ++i) ctx->prev_nactive[i] = (long long)st[11 + kMaxIter + i];
+  ctx->prev_tail_iter = ctx->tail_iter;
+  ctx->have_prev_nactive = true;
+  ctx->stats.tail_iter = ctx->tail_iter;
+  ctx->stats.tail_points = (ctx->tail_iter >= 0 && ctx->tail_iter < kMaxIter) ? (unsigned long long)st[11 + kMaxIter + ctx->tail_iter] : 0ull;
   // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
   // covers an underestimate
-  if (ctx->adaptive_iters) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
+  if (ctx->adaptive_iters && ctx->tail_iter < 0) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
   if (ctx->profile) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
@@ -681,6 +756,7 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
     };
     merged(ctx->refine_events, ctx->stats.solve_ms, ctx->stats.solve_ms_sum);
     merged(ctx->round_events, ctx->stats.round_ms, ctx->stats.round_ms_sum);
+    merged(ctx->tail_events, ctx->stats.tail_ms, ctx->stats.tail_ms_sum);
   }
   if (st[4]) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite per-point result on the device");
   return SVSDF_OK;
@@ -745,29 +821,37 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   // evaluations and without depending on the box.)
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
   if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; }
-  // Batch count (large shards in the scanning modes; DESIGN.md "concurrent point batches"): whether 4 batches beat 1
-  // depends on how the HIP runtime maps the batch streams onto hardware queues (GPU_MAX_HW_QUEUES, default 4: streams
-  // that share a queue serialise and the split is then SLOWER than one batch) -- a process-wide setting this library
-  // leaves to the host.  So the count is measured: after the bound mode is known, one evaluation learns the launch
-  // plan, then one evaluation per candidate (1, 4 [2 in the lazy mode], 3) is timed with the wall clock and the
-  // fastest count stays.  Every candidate computes the same bits; the choice only costs time.
+  // Batch count (large shards in the scanning modes; DESIGN.md "concurrent point batches").  Default: a RULE -- 3 batches in
+  // the full-scan mode, 2 in the lazy mode, from 400 k points per device, 1 otherwise (what the measurements of rounds 3 - 4
+  // chose on every box; with the main stream that is at most 4 streams, the HIP runtime's default number of hardware
+  // queues) -- so that the plan is the same on every run and settled after the deciding evaluation.  svsdf_set_plan
+  // (batches = -1) / SVSDF_BATCHES=measure ask for a measurement instead: after one evaluation that learns the launch
+  // widths, every candidate count (1, 4 [2 in the lazy mode], 3) runs three evaluations, timed with HIP events on the
+  // library's own stream (device time, not the host's wall clock), and the best median stays.  Every count computes the
+  // same bits.  While svsdf_set_profiling(ctx, 2) holds the batches serialised, nothing is measured or changed.
   int rc = SVSDF_OK;
-  const bool timing = ctx->bt_state >= 2;
+  const bool timing = ctx->bt_state >= 2 && ctx->saved_nbatch == 0;
   if (timing) rc = set_batches(ctx, ctx->bt_cand[ctx->bt_k]);
-  const auto t0 = std::chrono::steady_clock::now();
   if (rc == SVSDF_OK) rc = evaluate_points(ctx, N, coeffs, T, /*allow_cull=*/true, /*with_partial=*/true);
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (rc == SVSDF_OK && ctx->bt_state == 1) {
+  if (rc == SVSDF_OK && ctx->bt_state == 1 && ctx->saved_nbatch == 0) {
     ctx->bt_state = 2;
     ctx->bt_k = 0;
+    ctx->bt_rep = 0;
   } else if (rc == SVSDF_OK && timing) {
-    ctx->bt_ms[ctx->bt_k] = ms;
-    if (++ctx->bt_k == ctx->bt_ncand) {
-      int best = 0;
-      for (int k = 1; k < ctx->bt_ncand; ++k)
-        if (ctx->bt_ms[k] < ctx->bt_ms[best]) best = k;
-      rc = set_batches(ctx, ctx->bt_cand[best]);
-      ctx->bt_state = 0;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
+    ctx->bt_samples[ctx->bt_rep++] = ms;
+    if (ctx->bt_rep == 3) {
+      std::sort(ctx->bt_samples, ctx->bt_samples + 3);
+      ctx->bt_ms[ctx->bt_k] = ctx->bt_samples[1];
+      ctx->bt_rep = 0;
+      if (++ctx->bt_k == ctx->bt_ncand) {
+        int best = 0;
+        for (int k = 1; k < ctx->bt_ncand; ++k)
+          if (ctx->bt_ms[k] < ctx->bt_ms[best]) best = k;
+        rc = set_batches(ctx, ctx->bt_cand[best]);
+        ctx->bt_state = 0;
+      }
     }
   }
   if (rc == SVSDF_OK && deciding) {
@@ -776,19 +860,23 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_ratio = ctx->stats.gsip_samples ? (double)gs / (double)ctx->stats.gsip_samples : 0.0;
     // Polygon: an SDF evaluation costs several times an analytic shape's (candidate edges of the outline), a table
     // scan proportionally less of a solve, so scanning pays from a lower ratio
-    const double thr = ctx->ub_thr_env ? ctx->ub_threshold : (ctx->cfg.shape_id == SVSDF_SHAPE_Polygon ? 0.2 : ctx->ub_threshold);
+    const double thr = ctx->cfg.shape_id == SVSDF_SHAPE_Polygon ? 0.2 : ctx->ub_threshold;
     // below the threshold a large shard still gains from scanning -- but only the samples the cheap bound would have
     // had solved (lazy mode: NS, star / 16 pieces / 1 M points, 12.3 -> 11.4 ms; at 100 k points no gain)
     const bool large = ctx->P >= 400000;
     ctx->ub_full = ctx->ub_ratio > thr || large;
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
-    if (ctx->ub_full) ctx->have_prev_nsolve = false;   // the launch plan on record is the cheap-bound one
-    ctx->ub_tune = 1;
+    if (ctx->ub_full) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }   // the launch plan on record is the cheap-bound one
   }
-  // the batch count is measured once per point set, also when the bound mode was pinned by the environment
-  if (rc == SVSDF_OK && (deciding || (ctx->ub_env && ctx->ub_tune == 0))) {
+  // the batch count follows once the bound mode is known (also when it was pinned)
+  if (rc == SVSDF_OK && ctx->ub_tune == 0) {
     ctx->ub_tune = 1;
-    if (ctx->ub_full && ctx->want_batches == 0 && ctx->P >= 400000) {
+    const bool big = ctx->ub_full && ctx->P >= 400000;
+    if (ctx->want_batches == 0) {
+      const int nb = big ? (ctx->ub_lazy ? 2 : 3) : 1;
+      if (ctx->saved_nbatch > 0) ctx->saved_nbatch = nb;        // (serialised for profiling: takes effect when that ends)
+      else if (nb != ctx->nbatch) rc = set_batches(ctx, nb);
+    } else if (ctx->want_batches < 0 && big) {
       ctx->bt_state = 1;
       ctx->bt_cand[0] = 1;
       ctx->bt_cand[1] = ctx->ub_lazy ? 2 : 4;
@@ -1044,7 +1132,7 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   ctx->points_set = true;
   // batches: contiguous ranges of the sorted shard, pipelined on separate streams (one until the GSIP bound mode is
   // known, see set_batches)
-  int rcb = set_batches(ctx, ctx->want_batches > 0 ? ctx->want_batches : 1);
+  int rcb = set_batches(ctx, ctx->want_batches > 0 ? ctx->want_batches : 1);   // (rule / measurement: after the bound mode, run_pipeline_leaf)
   if (rcb) return rcb;
   // lanes per query: an evaluation is a chain of ~10 dependent solve launches, each a chain of ~100 dependent
   // group steps.  Small shards cannot fill the GPU and are pure latency: wide groups shorten the chains
@@ -1052,6 +1140,8 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   // fewer lanes (2 since round 3: the ladders share the wave's lanes anyway, so the width only shapes the scan layers and
   // the derivative).  Measured crossovers (tools/latency.py, tools/sweep.py): 3e3, 2e4, 3e5 points.
   ctx->have_prev_nsolve = false;
+  ctx->have_prev_nactive = false;
+  ctx->prev_tail_iter = -1;
   ctx->ub_tune = 0;
   ctx->bt_state = 0;
   ctx->ub_ratio = 0.0;
@@ -1126,6 +1216,7 @@ struct RcclApi {
   int (*CommDestroy)(void *comm) = nullptr;
   int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void *comm, int *count) = nullptr;
   bool load() {
     if (h) return true;
     // RCCL must come from the same ROCm tree as the HIP/HSA runtime this library is bound to: its init dlopen()s
@@ -1161,6 +1252,7 @@ struct RcclApi {
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(h, "ncclCommCount"));
     return CommInitAll && CommDestroy && AllReduce;
   }
 };
@@ -1180,6 +1272,10 @@ void merge_stats(svsdf_ctx *ctx) {
     t.device_ms = std::max(t.device_ms, a.device_ms); t.solve_ms = std::max(t.solve_ms, a.solve_ms);
     t.solve_ms_sum = std::max(t.solve_ms_sum, a.solve_ms_sum);
     t.solve_launches = std::max(t.solve_launches, a.solve_launches);
+    t.tail_launches = std::max(t.tail_launches, a.tail_launches);
+    t.tail_iter = std::max(t.tail_iter, a.tail_iter);
+    t.tail_points += a.tail_points;
+    t.tail_ms = std::max(t.tail_ms, a.tail_ms); t.tail_ms_sum = std::max(t.tail_ms_sum, a.tail_ms_sum);
     t.gsip_iterations = std::max(t.gsip_iterations, a.gsip_iterations);
     t.gsip_bound_mode = std::max(t.gsip_bound_mode, a.gsip_bound_mode);
     t.piece_time_exact = std::max(t.piece_time_exact, a.piece_time_exact);
@@ -1291,16 +1387,43 @@ double shape_circumradius(int shape_id, const double *poly_xy, int nverts) {
   }
 }
 
+// RCCL side of an in-process group: one communicator rank per sub-context (ncclCommInitAll over the group's devices),
+// an all-reduce output buffer per device and one pinned read-back buffer.  Returns an error text, empty on success.
+std::string group_init_rccl(svsdf_ctx *g) {
+  if (!g->comms.empty()) return "";
+  const int G = (int)g->subs.size();
+  std::vector<int> devs(G);
+  bool distinct = true;
+  for (int k = 0; k < G; ++k) {
+    devs[k] = g->subs[k]->device;
+    for (int j = 0; j < k; ++j) distinct = distinct && devs[j] != devs[k];
+  }
+  if (!distinct) return "SVSDF_COMBINE_RCCL needs distinct devices (one communicator rank per GPU)";
+  if (!g_rccl.load()) return "librccl.so could not be loaded (SVSDF_COMBINE_RCCL)";
+  g->comms.assign(G, nullptr);
+  {
+    const hipError_t stale = hipGetLastError();   // RCCL's init treats any pending (sticky-until-read) HIP error as its own
+    if (stale != hipSuccess && std::getenv("SVSDF_DEBUG")) std::fprintf(stderr, "[svsdf] cleared pending HIP error before ncclCommInitAll: %s\n", hipGetErrorString(stale));
+  }
+  const int e = g_rccl.CommInitAll(g->comms.data(), G, devs.data());
+  if (e) { g->comms.clear(); return std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); }
+  g->d_red.assign(G, nullptr);
+  for (int k = 0; k < G; ++k)
+    if (hipSetDevice(devs[k]) != hipSuccess || hipMalloc((void **)&g->d_red[k], kOutPartial * sizeof(double)) != hipSuccess)
+      return "allocation of the all-reduce buffer failed";
+  if (!g->h_red && hipHostMalloc((void **)&g->h_red, kOutPartial * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    return "pinned allocation failed";
+  return "";
+}
+
 // In-process multi-GPU context: one single-device sub-context (and one host thread) per entry of cfg->devices.
 svsdf_ctx *create_group(const svsdf_config *cfg, int ndev) {
   const int G = cfg->n_devices;
-  bool distinct = true;
   for (int k = 0; k < G; ++k) {
     if (cfg->devices[k] < 0 || cfg->devices[k] >= ndev) {
       g_last_error = "svsdf_create: devices[" + std::to_string(k) + "] is not a visible HIP device";
       return nullptr;
     }
-    for (int j = 0; j < k; ++j) distinct = distinct && cfg->devices[j] != cfg->devices[k];
   }
   svsdf_ctx *g = new svsdf_ctx();
   g->cfg = *cfg;
@@ -1326,21 +1449,8 @@ svsdf_ctx *create_group(const svsdf_config *cfg, int ndev) {
   }
   g->r_bound = g->subs[0]->r_bound;
   if (g->combine == SVSDF_COMBINE_RCCL) {
-    if (!distinct) return bail("svsdf_create: SVSDF_COMBINE_RCCL needs distinct devices (one communicator rank per GPU)");
-    if (!g_rccl.load()) return bail("svsdf_create: librccl.so could not be loaded (SVSDF_COMBINE_RCCL)");
-    g->comms.assign(G, nullptr);
-    {
-      const hipError_t stale = hipGetLastError();   // RCCL's init treats any pending (sticky-until-read) HIP error as its own
-      if (stale != hipSuccess && std::getenv("SVSDF_DEBUG")) std::fprintf(stderr, "[svsdf] cleared pending HIP error before ncclCommInitAll: %s\n", hipGetErrorString(stale));
-    }
-    const int e = g_rccl.CommInitAll(g->comms.data(), G, cfg->devices);
-    if (e) { g->comms.clear(); return bail(std::string("svsdf_create: ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error")); }
-    g->d_red.assign(G, nullptr);
-    for (int k = 0; k < G; ++k)
-      if (hipSetDevice(cfg->devices[k]) != hipSuccess || hipMalloc((void **)&g->d_red[k], kOutPartial * sizeof(double)) != hipSuccess)
-        return bail("svsdf_create: allocation of the all-reduce buffer failed");
-    if (hipHostMalloc((void **)&g->h_red, kOutPartial * sizeof(double), hipHostMallocDefault) != hipSuccess)
-      return bail("svsdf_create: pinned allocation failed");
+    const std::string e = group_init_rccl(g);
+    if (!e.empty()) return bail("svsdf_create: " + e);
   }
   return g;
 }
@@ -1483,7 +1593,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_late = g; ctx->G_late_env = g; } }
   if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; ctx->block_env = true; }
-  if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
+  if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = (std::string(e) == "measure") ? -1 : std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
   if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
   if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) { ctx->delta_all_iter = std::atoi(e); ctx->all_iter_env = true; }
   if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
@@ -1495,6 +1605,9 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
+  if (const char *e = std::getenv("SVSDF_TAIL")) ctx->tail_mode = (std::string(e) == "off") ? -2 : (std::string(e) == "auto") ? -1 : std::max(0, std::atoi(e));
+  if (const char *e = std::getenv("SVSDF_TAIL_BELOW")) ctx->tail_below = std::atoll(e);
+  if (const char *e = std::getenv("SVSDF_TAIL_ALL_AFTER")) ctx->tail_all_after = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_ROUND_LIST")) ctx->round_list = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_lazy = std::atoi(e) == 2; ctx->ub_env = true; }
   if (const char *e = std::getenv("SVSDF_UB_RATIO")) { ctx->ub_threshold = std::atof(e); ctx->ub_thr_env = true; }
@@ -1764,6 +1877,81 @@ int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]) {
   const svsdf_ctx *c = ctx->subs.empty() ? ctx : ctx->subs[0];
   out2[0] = c->r_bound;
   out2[1] = c->r_bound_sampled;
+  return SVSDF_OK;
+}
+
+int svsdf_get_plan(const svsdf_ctx *ctx, svsdf_plan *out) {
+  if (!ctx || !out) return SVSDF_ERR_INVALID;
+  const svsdf_ctx *c = ctx->subs.empty() ? ctx : ctx->subs[0];
+  out->bound_mode = c->ub_full ? (c->ub_lazy ? 2 : 1) : 0;
+  out->batches = (c->saved_nbatch > 0) ? c->saved_nbatch : c->nbatch;
+  out->lanes_per_query = c->G;
+  out->tail_iter = (c->tail_mode == -2) ? -2 : (c->tail_mode >= 0) ? c->tail_mode : (c->have_prev_nactive ? choose_tail_iter(c) : SVSDF_PLAN_AUTO);
+  out->settled = ((c->ub_env || c->ub_tune > 0) && c->bt_state == 0 && c->have_prev_nsolve) ? 1 : 0;
+  return SVSDF_OK;
+}
+
+int svsdf_set_plan(svsdf_ctx *ctx, const svsdf_plan *plan) {
+  if (!ctx || !plan) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_plan: null argument");
+  const int g = plan->lanes_per_query;
+  if (plan->bound_mode < SVSDF_PLAN_AUTO || plan->bound_mode > 2 || plan->batches < -2 || plan->batches == 0 || plan->batches > kMaxBatches ||
+      !(g == SVSDF_PLAN_AUTO || g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) || plan->tail_iter < -2 || plan->tail_iter >= kMaxIter)
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_plan: field out of range");
+  if (!ctx->subs.empty()) {
+    int rc = SVSDF_OK;
+    for (svsdf_ctx *s : ctx->subs) { const int r = svsdf_set_plan(s, plan); if (r && !rc) { rc = r; ctx->err = s->err; } }
+    return rc;
+  }
+  if (ctx->host_only) return SVSDF_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  // bound mode: a change invalidates the launch widths on record (they belong to the other mode's solve counts)
+  if (plan->bound_mode == SVSDF_PLAN_AUTO) {
+    if (ctx->ub_env) { ctx->ub_env = false; ctx->ub_tune = 0; ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }
+  } else {
+    const bool full = plan->bound_mode != 0, lazy = plan->bound_mode == 2;
+    if (!ctx->ub_env || full != ctx->ub_full || lazy != ctx->ub_lazy) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; ctx->ub_tune = 0; }
+    ctx->ub_env = true; ctx->ub_full = full; ctx->ub_lazy = lazy;
+  }
+  ctx->want_batches = (plan->batches == SVSDF_PLAN_AUTO) ? 0 : (plan->batches == -2) ? -1 : plan->batches;
+  ctx->bt_state = 0;
+  if (ctx->want_batches <= 0) ctx->ub_tune = 0;   // rule / measurement run again after the next evaluation
+  else if (ctx->points_set) {
+    if (ctx->saved_nbatch > 0) ctx->saved_nbatch = ctx->want_batches;
+    else if (ctx->nbatch != ctx->want_batches) { const int rc = set_batches(ctx, ctx->want_batches); if (rc) return rc; }
+  }
+  ctx->G_env = (g == SVSDF_PLAN_AUTO) ? 0 : g;
+  if (ctx->G_env) { ctx->G = g; if (!ctx->G_late_env) ctx->G_late = std::max(g, 8); }
+  else if (ctx->points_set) {
+    const size_t Ps = ctx->P;
+    ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : (ctx->cfg.shape_id == (int)kPolygon) ? 4 : 2;
+    if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
+  }
+  ctx->tail_mode = (plan->tail_iter == SVSDF_PLAN_AUTO) ? -1 : plan->tail_iter;
+  return SVSDF_OK;
+}
+
+int svsdf_set_combine(svsdf_ctx *ctx, int combine) {
+  if (!ctx || ctx->subs.empty()) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_combine: not a multi-device context");
+  if (combine != SVSDF_COMBINE_HOST && combine != SVSDF_COMBINE_RCCL) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_combine: unknown mode");
+  if (combine == SVSDF_COMBINE_RCCL) {
+    const std::string e = group_init_rccl(ctx);
+    if (!e.empty()) return fail(ctx, SVSDF_ERR_RCCL, "svsdf_set_combine: " + e);
+  }
+  ctx->combine = combine;
+  return SVSDF_OK;
+}
+
+int svsdf_group_info(const svsdf_ctx *ctx, int *n_devices, int *combine, int *rccl_ranks) {
+  if (!ctx) return SVSDF_ERR_INVALID;
+  if (n_devices) *n_devices = ctx->subs.empty() ? 1 : (int)ctx->subs.size();
+  if (combine) *combine = ctx->subs.empty() ? SVSDF_COMBINE_HOST : ctx->combine;
+  if (rccl_ranks) {
+    *rccl_ranks = 0;   // no communicator
+    if (!ctx->comms.empty() && ctx->comms[0] && g_rccl.CommCount) {
+      int n = 0;
+      if (g_rccl.CommCount(ctx->comms[0], &n) == 0) *rccl_ranks = n;   // asked of the communicator itself
+    }
+  }
   return SVSDF_OK;
 }
 

@@ -92,9 +92,16 @@ struct BatchCtl {
   StatSlot stat[kStatSlots];
 };
 
+// Piece durations for wave-uniform indices: the same T[] of the TrajDev in global memory, read through the constant
+// address space, i.e. with scalar loads (s_load_dwordx8: four durations per instruction into SGPRs, no VALU or LDS
+// issue slot).  Only kernels launched AFTER the k_prep that wrote them may use it (the scalar cache is not coherent
+// with stores of the running kernel).
+typedef const __attribute__((address_space(4))) double *UniformDoubles;
+
 // LDS view of the trajectory
 struct TrajL {
   const double *T, *S, *c;
+  UniformDoubles Tu;   // T[] for wave-uniform indices (scalar loads); see chain_local_time
   int N;
   int exact;
   double dur;
@@ -112,6 +119,7 @@ __device__ __forceinline__ TrajL stage_traj(const TrajDev *__restrict__ g, doubl
   __syncthreads();
   TrajL tr;
   tr.T = T; tr.S = S; tr.c = c; tr.N = N; tr.dur = g->dur; tr.exact = g->exact;
+  tr.Tu = (UniformDoubles)(g->T);
   return tr;
 }
 
@@ -263,6 +271,80 @@ struct PieceCache {
 };
 __device__ __forceinline__ PieceCache piece_cache_init() { PieceCache pc; pc.piece = 0; pc.lo = 1.0; pc.hi = 0.0; return pc; }
 
+// The reference's chain of subtractions (TRJ:498-516): r_0 = t, r_{j+1} = r_j - T_j, without the comparisons for
+// j < nb = piece - 1 (see pose_at), with them from there on.
+//  * Uniform phase.  Every lane walks the SAME index j, so the durations are wave-uniform operands: a window of 8 is
+//    fetched in one go (LDS reads at a uniform address; SVSDF_CHAIN == 2: scalar loads into SGPRs) and a step is one
+//    v_add_f64 for the whole wave, in blocks of four while every active lane still has four comparison-free steps left,
+//    then singly until the first lane reaches its nb.  Neighbouring queries sit in the same or adjacent pieces: almost
+//    the whole chain.
+//  * Per-lane rest: the lanes that are further along finish their comparison-free steps (LDS reads, divergent).
+//  * Comparisons: normally exactly two -- r > T[piece - 1] holds, r > T[piece] does not -- on two durations the caller
+//    fetched per lane BEFORE the chain (their LDS latency runs under the uniform phase, like that of the piece's
+//    coefficients); anything else (rounding moved t across a piece boundary) continues the reference's loop as written.
+// Same operations on the same operands in the same order as the per-lane loop of rounds 1-3: identical bits.
+// Round 4 measured what this buys and what it cannot: k_solve is VALU/scalar-issue bound and a chain of nb dependent
+// additions is nb instructions no form can drop (profiles/r04_chain_*: + 7 % at 32 pieces for the additions alone);
+// the per-lane loop of rounds 1-3 cost + 22 / + 28 % (C3 / NS), this form + 20 / + 20 %; straight-line predicated blocks
+// with scalar-loaded windows of 16 + 17 / + 18 % but 3 % on the cumulative-time path.
+#ifndef SVSDF_CHAIN
+#define SVSDF_CHAIN 3   // where the window comes from: 2 scalar loads (TrajL::Tu), 3 LDS (uniform address)
+#endif
+struct ChainWin { double w[8]; };
+__device__ __forceinline__ ChainWin chain_window(const TrajL &tr, int jb) {
+  ChainWin c;
+#if SVSDF_CHAIN == 2
+  const UniformDoubles Tu = tr.Tu + jb;      // (may read a few doubles past T[N - 1]: still inside TrajDev)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c.w[k] = Tu[k];
+#else
+  const double *Tl = tr.T + jb;              // (may read a few doubles past T[N - 1]: S[] follows in LDS)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c.w[k] = Tl[k];
+#endif
+  return c;
+}
+__device__ __forceinline__ double chain_local_time(const TrajL &tr, double t, int piece, double tprev, double tcur, ChainWin w, int &idx) {
+  const int N = tr.N;
+  const int nb = (tr.exact == 2) ? 0 : piece - 1;
+  double r = t;
+  int j = 0;
+  for (int jb = 0;; jb += 8) {   // wave-uniform
+    if (jb) w = chain_window(tr, jb);
+    if (__all(nb >= jb + 4)) {
+      r = (((r - w.w[0]) - w.w[1]) - w.w[2]) - w.w[3];
+      j = jb + 4;
+      if (__all(nb >= jb + 8)) {
+        r = (((r - w.w[4]) - w.w[5]) - w.w[6]) - w.w[7];
+        j = jb + 8;
+        continue;
+      }
+      if (__all(nb > j)) { r -= w.w[4]; ++j; if (__all(nb > j)) { r -= w.w[5]; ++j; if (__all(nb > j)) { r -= w.w[6]; ++j; } } }
+    } else {
+      if (__all(nb > j)) { r -= w.w[0]; ++j; if (__all(nb > j)) { r -= w.w[1]; ++j; if (__all(nb > j)) { r -= w.w[2]; ++j; } } }
+    }
+    break;
+  }
+  for (int jj = j; jj < nb; ++jj) r -= tr.T[jj];   // per lane: the lanes further along than the wave's first
+  int jj = piece;
+  if (tr.exact == 2) {
+    jj = 0;   // (some piece shorter than 1e-6 s: every step with its comparison)
+  } else {
+    if (piece > 0) {
+      if (!(r > tprev)) { idx = piece - 1; return r; }
+      r -= tprev;
+    }
+    if (!(r > tcur)) { idx = piece; return r; }
+    r -= tcur;
+    ++jj;
+  }
+  double dur_ = 0.0;
+  for (; jj < N && r > (dur_ = tr.T[jj]); ++jj) r -= dur_;
+  if (jj == N) { --jj; r += tr.T[jj]; }   // past the end: the last piece, TRJ:510-514
+  idx = jj;
+  return r;
+}
+
 __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, PieceCache &pc) {
   if (tr.exact) {   // wave-uniform
     // Faithful piece-local time at the evaluation site.  The cached cumulative locate gives a candidate index ih
@@ -270,21 +352,29 @@ __device__ __forceinline__ Pose pose_at(const TrajL &tr, double t, PieceCache &p
     // j < ih - 1 -- there r_j - T_j ~ t - S_{j+1} >= T_{ih-1} > 0 by a margin of >= min T (host: >= 1e-6, else
     // exact == 2 and the full loop runs) against rounding of <= 64 ulp(t) -- and with them from there on, so index
     // and local time are the reference's to the last bit (TRJ:498-516).
+    const ChainWin w0 = chain_window(tr, 0);   // (issued first: in flight during the cache check)
     if (!(t > pc.lo && t <= pc.hi)) {
       pc.piece = locate_piece(tr, t, pc.piece);
       pc.lo = (pc.piece == 0) ? -1e300 : tr.S[pc.piece];
       pc.hi = (pc.piece == tr.N - 1) ? 1e300 : tr.S[pc.piece + 1];
     }
-    const int nb = (tr.exact == 2) ? 0 : pc.piece - 1;
-    double r = t;
-    int jj = 0;
-    for (; jj + 3 < nb; jj += 4) r = (((r - tr.T[jj]) - tr.T[jj + 1]) - tr.T[jj + 2]) - tr.T[jj + 3];
-    for (; jj < nb; ++jj) r -= tr.T[jj];
-    double dur_ = 0.0;
-    for (; jj < tr.N && r > (dur_ = tr.T[jj]); ++jj) r -= dur_;
-    if (jj == tr.N) { --jj; r += tr.T[jj]; }
+    // everything the chain's end needs is requested before the chain starts: the two durations its comparisons use and
+    // the coefficients of the piece it normally ends in (it ends elsewhere only when rounding moved t across a boundary)
+    const int piece = pc.piece;
+    const double tprev = tr.T[(piece > 0) ? piece - 1 : 0], tcur = tr.T[piece];
+    const double *cp = tr.c + piece * 18;
+    double cc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) cc[k] = cp[k];
+    int jj;
+    const double r = chain_local_time(tr, t, piece, tprev, tcur, w0, jj);
+    if (jj != piece) {
+      const double *cq = tr.c + jj * 18;
+#pragma unroll
+      for (int k = 0; k < 18; ++k) cc[k] = cq[k];
+    }
     double x_, y_, yaw_;
-    piece_pos(tr.c + jj * 18, r, x_, y_, yaw_);
+    piece_pos(cc, r, x_, y_, yaw_);
     Pose p_;
     p_.x = x_; p_.y = y_;
     sincos_exact(yaw_, &p_.sn, &p_.cs);
@@ -1706,6 +1796,186 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_tail: ALL remaining GSIP iterations of a batch in one launch (from iteration `it0` on, i.e. the launches
+// R_it0 S_it0 R_it0+1 ... of the chain).  A GSIP point is independent of every other point, so once the active set is small
+// the launch chain -- two kernels per iteration, each ending in a tail where the chip drains, ~10 iterations -- only
+// costs latency.  Here a half-wave (32 lanes, lane j <-> circle sample j, round_point<.., 32, ..>) OWNS a point until it
+// is finished:  close the round -> open the next -> select -> solve the selected samples IN THE WAVE -> close ... .  No
+// hand-off between workgroups, no list atomics, no block barrier after the table staging; a half-wave that has finished
+// its point takes the next one from the active list.  The solves of the wave's two points run together: the wave's
+// <= 48 selected samples are dealt out to lane groups of 8 (up to 8 queries) or 2 lanes, each group runs the very
+// scan_layer1 / descend_from_seed of k_solve (the descent's ladders share the wave as there).  Same per-sample and
+// per-point arithmetic as the launch chain, so identical bits whatever it0 is (the host picks it from the previous
+// evaluation's active counts).
+//  * `prev_mode`: bound mode (k_round MODE) of the launch chain that opened the rounds this kernel finds open: decides
+//    whether those samples carry a scan seed (sq_k); rounds opened here follow MODE.
+//  * selection band: `delta` for the first `all_after` steps of a point in this kernel, everything afterwards.
+// LDS: [Polygon edges | pose table 4K | chunks 4 nch | trajectory 20N+1] doubles, then kTailWaveLds bytes per wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTailBlock = 256;
+constexpr int kTailFetch = 8;     // points a wave takes from the active list per atomic
+constexpr size_t kTailWaveLds = ((ladder_lds_bytes(2) + 15) & ~(size_t)15) + 2 * kMaxCand * sizeof(unsigned short) + 64 * sizeof(unsigned);
+template <int SHAPE, int G>
+__device__ __forceinline__ void tail_solve_pass(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
+                                                const Pose *pose, const Chunk *chunks, int K, int nch, const GsipState &gs,
+                                                const unsigned *qlist, int base, int nq, int prune, void *wave_lds,
+                                                unsigned &n_eval, unsigned &n_scan, unsigned &n_solved, unsigned &n_spec) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int li = Grp<G>::li();
+  const int q = base + lane / G;
+  const bool live = q < nq;
+  unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  size_t slot = 0;
+  double px = 0.0, py = 0.0;
+  double best_d = 1e9;
+  int best_k = 0x7fffffff;
+  if (live) {
+    const unsigned e = qlist[q];
+    slot = (size_t)(e & 0x7fffffffu);
+    px = gs.sqx[slot]; py = gs.sqy[slot];
+    const bool seeded = (e >> 31) != 0u;
+    if (seeded) { best_k = gs.sq_k[slot]; best_d = gs.sq_ub[slot]; }
+    if (!seeded || best_k < 0) {
+      bool culled;
+      scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, __longlong_as_double(0x7ff0000000000000ll), best_d, best_k,
+                            culled, n_scan, nullptr, -1, nullptr);
+    }
+  }
+  double x = 0.0, fx = 0.0;
+  descend_from_seed<SHAPE, G, 1>(tr, tk, sp, px, py, live, best_k, best_d, x, fx, n_eval, n_spec, sc, wave_lds);   // whole wave
+  if (live && li == 0) {
+    gs.sq_sdf[slot] = fx;
+    gs.sq_t[slot] = x;
+    ++n_solved;
+  }
+}
+
+#ifndef SVSDF_TAIL_WAVES
+#define SVSDF_TAIL_WAVES 3   // waves per SIMD the register allocation aims at (168 VGPRs)
+#endif
+template <int SHAPE, int MODE>
+__global__ void __launch_bounds__(kTailBlock, SVSDF_TAIL_WAVES)
+k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
+       const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_, const double *__restrict__ py_,
+       GsipState gs, size_t stride, int it0, int prev_mode, double delta, double band_delta, int all_after,
+       double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
+       BatchCtl *__restrict__ ctl, int clist_on, int prune) {
+  extern __shared__ double tail_lds[];
+  constexpr int LP = 32;
+  const int n_act = ctl->n_active[it0];
+  const int wave_g = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (n_act <= 0 || (int)blockIdx.x * (kTailBlock / 64) * 2 >= n_act) return;   // block-uniform
+  const int K = trg->K;
+  const int nch = (K + kChunk - 1) / kChunk;
+  stage_poly_edges<SHAPE>(sp, tail_lds);
+  double *tab_lds = tail_lds + poly_lds_doubles<SHAPE>(sp.nverts);
+  Pose *pose = reinterpret_cast<Pose *>(tab_lds);
+  Chunk *chunks = reinterpret_cast<Chunk *>(tab_lds + 4 * (size_t)K);
+  {
+    const double *src = reinterpret_cast<const double *>(pose_g);
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) tab_lds[i] = src[i];
+    const double *srcc = reinterpret_cast<const double *>(chunks_g);
+    for (int i = threadIdx.x; i < 4 * nch; i += blockDim.x) tab_lds[4 * (size_t)K + i] = srcc[i];
+  }
+  const TrajL tr = stage_traj(trg, tab_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads (the only block barrier)
+  const size_t tables = poly_lds_doubles<SHAPE>(sp.nverts) + 4 * (size_t)K + 4 * (size_t)nch + (size_t)traj_lds_doubles(tr.N);
+  char *wave_lds = reinterpret_cast<char *>(tail_lds + ((tables + 1) & ~(size_t)1)) + (threadIdx.x >> 6) * kTailWaveLds;
+  unsigned short *clist_w = reinterpret_cast<unsigned short *>(wave_lds + ((ladder_lds_bytes(2) + 15) & ~(size_t)15));
+  unsigned *qlist = reinterpret_cast<unsigned *>(clist_w + 2 * kMaxCand);
+  const int start = ctl->start;
+  const int *cur = gs.list[it0 & 1] + start;
+  const int lane = (int)(threadIdx.x & 63);
+  const int h = lane >> 5, l = lane & (LP - 1);
+  const unsigned lt_mask = (1u << l) - 1u;
+  unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_spec = 0, n_rscan = 0;
+  unsigned long long rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  int n_emit_tot = 0;
+  // work: the wave's first two points are its own (wave index: no atomic), further ones come kTailFetch at a time
+  const int n_static = (int)(gridDim.x * (blockDim.x >> 6)) * 2;
+  int q_next = wave_g * 2, q_end = min(wave_g * 2 + 2, n_act);   // wave-uniform
+  bool exhausted = false;
+  int a = -1;          // interior index of this half's point (-1: none)
+  int steps = 0;       // GSIP steps this half's point has taken in this kernel
+  bool own = false;    // the open round of this half's point was opened here (MODE) and not by the launch chain (prev_mode)
+  for (int guard = 0; guard < (1 << 24); ++guard) {
+    // ---- refill: a half without a point takes the next one
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int ah = __builtin_amdgcn_readlane(a, hh * 32);
+      if (ah >= 0) continue;
+      if (q_next >= q_end && !exhausted) {
+        unsigned b = 0;
+        if (lane == 0) b = atomicAdd(&ctl->work[min(it0 + 1, kWorkCounters - 1)], (unsigned)kTailFetch);
+        b = __builtin_amdgcn_readfirstlane(b);
+        const long long bb = (long long)b + n_static;
+        if (bb >= n_act) exhausted = true;
+        else { q_next = (int)bb; q_end = (int)min((long long)n_act, bb + kTailFetch); }
+      }
+      if (q_next < q_end) {
+        const int e = q_next++;
+        if (h == hh) { a = cur[e]; steps = 0; own = false; }
+      }
+    }
+    if (__builtin_amdgcn_readlane(a, 0) < 0 && __builtin_amdgcn_readlane(a, 32) < 0) break;
+    // ---- one GSIP step per half: close / finish / open + select (k_round's round_point, 32 lanes per point)
+    RoundOut<1> ro;
+    ro.list_me[0] = false; ro.mlist[0] = 0u; ro.n_emit = 0; ro.push_next = false; ro.finished = false;
+    if (a >= 0) {
+      const double dl = (steps >= all_after) ? 1e300 : delta, bd = (steps >= all_after) ? 1e300 : band_delta;
+      round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, dl, bd, res_sdf, res_t, res_gx,
+                                   res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc);
+      ++steps;
+      if (ro.n_emit > 0) own = true;
+      if (l == 0) n_emit_tot += ro.n_emit;
+    }
+    const size_t ia = (size_t)start + (size_t)(a >= 0 ? a : 0);
+    if (ro.finished) a = -1;
+    // ---- the wave's solve list: the selected samples of both halves
+    const unsigned m_mine = (a >= 0) ? ro.mlist[0] : 0u;
+    const int n0 = __popc((unsigned)__builtin_amdgcn_readlane((int)m_mine, 0));
+    const int n1 = __popc((unsigned)__builtin_amdgcn_readlane((int)m_mine, 32));
+    const int nq = n0 + n1;
+    if ((m_mine >> l) & 1u) {
+      const bool seeded = own ? (MODE != 0) : (prev_mode != 0);
+      qlist[(h ? n0 : 0) + __popc(m_mine & lt_mask)] = (unsigned)sample_slot(stride, ia, l) | (seeded ? 0x80000000u : 0u);
+    }
+    // the samples and the point state just written are read by other lanes of this wave, the solved values below by the
+    // next step's close
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (nq > 0) {
+      if (nq <= 8) {
+        tail_solve_pass<SHAPE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
+      } else {
+        for (int base = 0; base < nq; base += 32)
+          tail_solve_pass<SHAPE, 2>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, base, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+  unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tp = n_spec, tr_ = n_rscan;
+  int em = n_emit_tot;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    te += __shfl_xor(te, m, 64); ts += __shfl_xor(ts, m, 64); tc += __shfl_xor(tc, m, 64); tp += __shfl_xor(tp, m, 64);
+    tr_ += __shfl_xor(tr_, m, 64); em += __shfl_xor(em, m, 64);
+  }
+  if (lane == 0 && (te || tr_ || em)) {
+    StatSlot *ss = stat_slot(ctl->stat);
+    if (te) atomicAdd(&ss->evals, te);
+    if (ts) atomicAdd(&ss->solves, ts);
+    if (tc) atomicAdd(&ss->scan, tc);
+    if (tp) atomicAdd(&ss->spec, tp);
+    if (tr_) atomicAdd(&ss->round_scan, tr_);
+    if (em) atomicAdd(&ctl->n_seed[it0], em);
+    if (ts) atomicAdd(&ctl->n_solve[it0], (int)ts);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_assemble: loop body of BEO:786-865 for one point given (sdf, t*, grad_prel), then a
 // block-level segmented reduction keyed by piece.  Block partials are stored entry-major
 // ([entry][block]) so that k_final reads them coalesced.  Entries:
@@ -1872,6 +2142,11 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
     }
     stats_out[9 + kMaxIter] = rs;
     stats_out[10 + kMaxIter] = sp_;
+    for (int i = 0; i < kMaxIter; ++i) {   // active GSIP points per iteration: the host places the fused tail (k_tail) by them
+      unsigned long long na = 0;
+      for (int b = 0; b < nbatch; ++b) na += (unsigned long long)ctl[b].n_active[i];
+      stats_out[11 + kMaxIter + i] = na;
+    }
   }
 }
 

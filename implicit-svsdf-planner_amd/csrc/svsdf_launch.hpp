@@ -22,6 +22,11 @@ struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
   size_t stride; int it; double delta, band_delta; double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl;
   int clist_on;   // 1: scans / cheap bounds walk the per-point candidate-chunk list (0: all chunks; same results)
 };
+struct TailLaunch {    // arguments of k_tail<SHAPE, MODE>
+  const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py;
+  GsipState gs; size_t stride; int it0, prev_mode; double delta, band_delta; int all_after;
+  double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl; int clist_on, prune;
+};
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
   const TrajDev *traj; ShapeParams sp; const double *px, *py, *sdf, *t; double *res_sdf, *res_t, *res_gx, *res_gy;
   GsipState gs; BatchCtl *ctl;
@@ -31,6 +36,7 @@ struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
 bool launch_k_solve(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a);
 bool launch_k_round(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a);
 bool launch_k_classify(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a);
+bool launch_k_tail(int shape, int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunch &a);
 bool launch_k_rbound(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out);
 bool launch_k_subsw(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,
                     const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);
@@ -42,6 +48,7 @@ bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParam
   bool launch_k_solve_s##K(int shape, int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, const SolveLaunch &a); \
   bool launch_k_round_s##K(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a);      \
   bool launch_k_classify_s##K(int shape, unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a);                  \
+  bool launch_k_tail_s##K(int shape, int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunch &a);                \
   bool launch_k_rbound_s##K(int shape, unsigned grid, hipStream_t st, ShapeParams sp, double rmax, int nrad, int nang, double *out); \
   bool launch_k_subsw_s##K(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,    \
                            const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);         \

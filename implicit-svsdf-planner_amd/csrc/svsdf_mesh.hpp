@@ -8,7 +8,8 @@
 // svsdf_config::polygon_xy takes: every triangle that straddles the plane contributes the segment between its two
 // crossed edges; crossing points are keyed by the (undirected) mesh edge they lie on, so neighbouring triangles share
 // them exactly and the segments chain into closed loops without any tolerance.  A vertex exactly on the plane counts
-// as above it.  The longest loop is returned (a closed, orientable mesh of one solid gives exactly one).
+// as above it.  The loop enclosing the largest area is returned (a closed, orientable mesh of one solid gives exactly
+// one loop; callers that plan with the outline must check `loops == 1`, see svsdf_traj_optimizer.hpp).
 #pragma once
 #include <cmath>
 #include <cstdio>
@@ -55,7 +56,7 @@ inline bool read_obj(const char *path, std::vector<double> &V, std::vector<int> 
 }
 
 // Outline of the cross-section z = z0 of the mesh (V: nv x 3, F: nf x 3 vertex indices).  xy_out: interleaved vertices
-// of the longest closed loop, in chaining order; loops_out (may be null): number of closed loops found.
+// of the closed loop with the largest |area|, in chaining order; loops_out (may be null): number of closed loops found.
 // Returns false on a malformed mesh (index out of range) or when no triangle straddles the plane.
 inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, double z0, std::vector<double> &xy_out,
                          int *loops_out) {
@@ -100,6 +101,7 @@ inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, do
   if (np < 3) return false;
   std::vector<char> seen(np, 0);
   std::vector<int> best;
+  double best_area = -1.0;
   int loops = 0;
   for (int s = 0; s < np; ++s) {
     if (seen[s]) continue;
@@ -117,7 +119,13 @@ inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, do
     }
     if (closed && loop.size() >= 3) {
       ++loops;
-      if (loop.size() > best.size()) best.swap(loop);
+      double a2 = 0.0;   // twice the signed area (shoelace)
+      for (size_t q = 0; q < loop.size(); ++q) {
+        const int u = loop[q], w = loop[(q + 1) % loop.size()];
+        a2 += px[u] * py[w] - px[w] * py[u];
+      }
+      // (a finely tessellated small part must not win over a coarse large one: by area, not by vertex count)
+      if (std::fabs(a2) > best_area) { best_area = std::fabs(a2); best.swap(loop); }
     }
   }
   if (loops_out) *loops_out = loops;

@@ -76,6 +76,21 @@ bool round_s(int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const 
 }
 
 template <int S>
+bool tail_s(int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunch &a) {
+  if constexpr (!kernel_shape_enabled<S>()) {
+    return false;
+  } else {
+#define TAIL(MODE)                                                                                                   \
+  hipLaunchKernelGGL((k_tail<S, MODE>), dim3(grid), dim3(kTailBlock), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp,  \
+                     a.px, a.py, a.gs, a.stride, a.it0, a.prev_mode, a.delta, a.band_delta, a.all_after, a.res_sdf,   \
+                     a.res_t, a.res_gx, a.res_gy, a.ctl, a.clist_on, a.prune)
+    if (mode == 2) TAIL(2); else if (mode == 1) TAIL(1); else TAIL(0);
+#undef TAIL
+    return true;
+  }
+}
+
+template <int S>
 bool classify_s(unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch &a) {
   if constexpr (!shape_enabled<S>()) {
     return false;
@@ -137,6 +152,11 @@ bool SLICE_FN(launch_k_solve)(int shape, int G, unsigned grid, unsigned block, s
 }
 bool SLICE_FN(launch_k_round)(int shape, int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const RoundLaunch &a) {
 #define CALL(S) round_s<S>(lp, mode, grid, lds, st, a)
+  SLICE_SWITCH(CALL)
+#undef CALL
+}
+bool SLICE_FN(launch_k_tail)(int shape, int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunch &a) {
+#define CALL(S) tail_s<S>(mode, grid, lds, st, a)
   SLICE_SWITCH(CALL)
 #undef CALL
 }

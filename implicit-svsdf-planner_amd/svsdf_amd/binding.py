@@ -29,6 +29,7 @@ EXPORTS = [
     "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
     "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline", "svsdf_outline_extrude",
+    "svsdf_get_plan", "svsdf_set_plan", "svsdf_set_combine", "svsdf_group_info",
 ]
 
 
@@ -65,7 +66,17 @@ class Stats(C.Structure):
                 ("n_devices", C.c_int), ("combine", C.c_int), ("combine_ms", C.c_double), ("setup_ms", C.c_double),
                 ("piece_time_exact", C.c_int), ("solve_ms_sum", C.c_double), ("round_scan_evals", C.c_ulonglong),
                 ("round_ms", C.c_double), ("round_ms_sum", C.c_double), ("batches", C.c_int),
-                ("speculative_evals", C.c_ulonglong), ("plan_settled", C.c_int)]
+                ("speculative_evals", C.c_ulonglong), ("plan_settled", C.c_int), ("tail_iter", C.c_int),
+                ("tail_launches", C.c_uint), ("tail_points", C.c_ulonglong), ("tail_ms", C.c_double),
+                ("tail_ms_sum", C.c_double)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("bound_mode", C.c_int), ("batches", C.c_int), ("lanes_per_query", C.c_int), ("tail_iter", C.c_int),
+                ("settled", C.c_int)]
+
+
+PLAN_AUTO = -1
 
 
 class OutlineStats(C.Structure):
@@ -157,6 +168,10 @@ def lib():
     L.svsdf_swept_outline.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, C.c_size_t,
                                       C.POINTER(C.c_size_t), _ip, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.POINTER(OutlineStats)]
+    L.svsdf_get_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
+    L.svsdf_set_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
+    L.svsdf_set_combine.argtypes = [C.c_void_p, C.c_int]
+    L.svsdf_group_info.argtypes = [C.c_void_p, _ip, _ip, _ip]
     _LIB = L
     return L
 
@@ -594,6 +609,29 @@ class SvsdfContext:
         o = np.zeros(2)
         self._chk(self.L.svsdf_shape_bound(self.ctx, _p(o)), "svsdf_shape_bound")
         return float(o[0]), float(o[1])
+
+    def get_plan(self):
+        """Launch plan in force (svsdf_get_plan): bound_mode, batches, lanes_per_query, tail_iter, settled."""
+        pl = Plan()
+        self._chk(self.L.svsdf_get_plan(self.ctx, C.byref(pl)), "svsdf_get_plan")
+        return {k: getattr(pl, k) for k, _ in Plan._fields_}
+
+    def set_plan(self, bound_mode=PLAN_AUTO, batches=PLAN_AUTO, lanes_per_query=PLAN_AUTO, tail_iter=PLAN_AUTO):
+        """Pin fields of the launch plan (svsdf_set_plan; PLAN_AUTO leaves a field to its rule; batches=-2: measured).
+        Only moves time: every plan returns the same bits."""
+        pl = Plan(int(bound_mode), int(batches), int(lanes_per_query), int(tail_iter), 0)
+        self._chk(self.L.svsdf_set_plan(self.ctx, C.byref(pl)), "svsdf_set_plan")
+
+    def set_combine(self, combine):
+        """Multi-device contexts: 'host' or 'rccl' sum of the devices' partials (svsdf_set_combine)."""
+        code = {"host": 1, "rccl": 2}.get(combine, combine)
+        self._chk(self.L.svsdf_set_combine(self.ctx, int(code)), "svsdf_set_combine")
+
+    def group_info(self):
+        """(devices, combine mode, ranks of the RCCL communicator as the communicator reports them; 0: none)."""
+        nd, cb, rk = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.svsdf_group_info(self.ctx, C.byref(nd), C.byref(cb), C.byref(rk)), "svsdf_group_info")
+        return {"n_devices": nd.value, "combine": ["auto", "host", "rccl"][cb.value], "rccl_ranks": rk.value}
 
     def set_profiling(self, enable=True):
         self._chk(self.L.svsdf_set_profiling(self.ctx, int(enable)), "svsdf_set_profiling")   # 2: serialised batches

@@ -97,7 +97,12 @@ class TrajOptimizer:
                 # reference's hard-coded rectangle (sw_manager.hpp:363-369), which the library substitutes itself
                 path = os.path.join(self.package_path, self.inputdata) if self.package_path else self.inputdata
                 if os.path.exists(path):
-                    polygon, _ = mesh_outline_obj(path)
+                    polygon, loops = mesh_outline_obj(path)
+                    if loops != 1:
+                        # several loops (disjoint bodies, a hole): planning with one of them would silently drop part of
+                        # the robot -- its collisions would go unpenalised
+                        raise SvsdfError(f"{path}: the z = 0 cross-section has {loops} closed loops; the Polygon shape "
+                                         "takes exactly one outline (pass `polygon=` explicitly to choose)")
             dist = _dist()
             rank, ws = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
             self._ctx = SvsdfContext(shape=sid, safety_hor=self.safety_hor, weight_p=self.weight_p,

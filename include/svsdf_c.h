@@ -376,8 +376,41 @@ typedef struct svsdf_stats {
   int plan_settled;                   /* 1 once bound mode, batch count and launch widths are fixed for this point set:
                                          the first evaluations after svsdf_set_points decide them (<= 6 evaluations, all
                                          with identical results); steady-state timing starts here */
+  int tail_iter;                      /* GSIP iteration from which the fused tail kernel (k_tail: every remaining iteration of a
+                                         batch in one launch, a half-wave owns a point until it is finished) took over; -1: none */
+  unsigned int tail_launches;         /* k_tail launches of the last evaluation (one per batch) */
+  unsigned long long tail_points;     /* GSIP points still active when the tail took over */
+  double tail_ms;                     /* HIP-event time during which >= 1 k_tail launch was executing (profiling on) */
+  double tail_ms_sum;                 /* plain sum of the k_tail launch durations (profiling on) */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
+
+/* Launch plan of the resident point set.  Every field only moves TIME: each setting returns the same bits (cost, gradient
+ * and per-point results).  By default everything follows deterministic rules: the first evaluation
+ * after svsdf_set_points runs with the cheap GSIP bound and decides the bound mode from its counters, the batch count
+ * follows from mode and shard size, the second evaluation records the launch widths; `settled` is 1 from then on.
+ * svsdf_set_plan pins fields (the AUTO value leaves a field to its rule) for this and every later point set of the
+ * context; svsdf_get_plan reports what is in force.  Multi-device contexts apply / report per device (get: device 0). */
+#define SVSDF_PLAN_AUTO (-1)
+typedef struct svsdf_plan {
+  int bound_mode;       /* GSIP upper-bound mode: 0 cheap chunk bound, 1 table scan of every sample, 2 lazy; SVSDF_PLAN_AUTO */
+  int batches;          /* concurrent point batches 1..8; SVSDF_PLAN_AUTO: by rule; -2: measured (three HIP-event timings
+                           per candidate count, best median) */
+  int lanes_per_query;  /* lanes of the main solve's lane groups: 1, 2, 4, 8, 16, 32; SVSDF_PLAN_AUTO: by shard size */
+  int tail_iter;        /* GSIP iteration from which the fused tail kernel runs: >= 0; -2: never; SVSDF_PLAN_AUTO: by rule */
+  int settled;          /* get only: 1 once nothing is left to decide for the resident point set */
+} svsdf_plan;
+int svsdf_get_plan(const svsdf_ctx *ctx, svsdf_plan *out);
+int svsdf_set_plan(svsdf_ctx *ctx, const svsdf_plan *plan);
+/* In-process multi-device contexts (svsdf_config::n_devices >= 2, or 1 with SVSDF_COMBINE_RCCL): switch how the devices'
+ * partials are summed -- SVSDF_COMBINE_HOST (fixed-order sum of the pinned partials) or SVSDF_COMBINE_RCCL (one
+ * ncclAllReduce per device thread; the communicator is created on first use, distinct devices required).  Both give the
+ * sum of the same G partials; the host form is bit-reproducible, RCCL's order is the library's.  Replaces, for this one
+ * sum, what the reference does in its OpenMP critical section (back_end_optimizer.hpp:855-863). */
+int svsdf_set_combine(svsdf_ctx *ctx, int combine);
+/* Devices driven by the context, combine mode in force, and the rank count of the RCCL communicator as reported by the
+ * communicator itself (ncclCommCount; 0 when none exists).  Any out pointer may be NULL. */
+int svsdf_group_info(const svsdf_ctx *ctx, int *n_devices, int *combine, int *rccl_ranks);
 /* Shape bound used by the exact scan pruning and the exact cull: out2[0] = R with sdf_shape(q) >= |q| - R
  * (analytic circumradius of the shape + |offset|, Shape.hpp:281-294 / :531-1476), out2[1] = the largest
  * |q| - sdf_shape(q) found on a polar grid out to 60 m at context creation (self-check: <= out2[0]). */

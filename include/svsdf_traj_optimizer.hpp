@@ -44,6 +44,7 @@ class TrajOptimizerHip {
   std::string inputdata = "shapes/star.obj";
   double poly_params[3] = {0.0, 0.0, 0.0};
   std::string package_path;        // what ros::package::getPath("plan_manager") returns (Shape.hpp:283): prefix of inputdata
+  std::string mesh_error;          // why context() returned nullptr for a mesh `inputdata` (cross-section with several loops)
   std::vector<double> polygon_xy;  // optional outline for the Polygon fallback; empty + an inputdata stem the shape
                                    // registry does not know -> the z = 0 outline of that .obj mesh (BASELINE config 5)
   int device = -1;
@@ -184,7 +185,10 @@ class TrajOptimizerHip {
         // igl::read_triangle_mesh, Shape.hpp:281-284); unreadable -> the reference's hard-coded rectangle (SWM:363-369)
         const std::string path = package_path.empty() ? inputdata : package_path + "/" + inputdata;
         std::size_t n = 0;
-        if (svsdf_mesh_outline_obj(path.c_str(), 0.0, nullptr, 0, &n, nullptr) == SVSDF_OK && n >= 3) {
+        int loops = 0;
+        if (svsdf_mesh_outline_obj(path.c_str(), 0.0, nullptr, 0, &n, &loops) == SVSDF_OK && n >= 3) {
+          // several loops (disjoint bodies, a hole): planning with one of them would silently drop part of the robot
+          if (loops != 1) { mesh_error = path + ": the z = 0 cross-section has " + std::to_string(loops) + " closed loops"; return nullptr; }
           outline.resize(2 * n);
           if (svsdf_mesh_outline_obj(path.c_str(), 0.0, outline.data(), n, &n, nullptr) != SVSDF_OK) outline.clear();
         }

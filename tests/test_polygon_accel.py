@@ -170,6 +170,26 @@ def test_obj_reader_and_errors(built, tmp_path):
     F2 = np.concatenate([F, np.concatenate([quads[:, [0, 1, 2]], quads[:, [0, 2, 3]]])]).astype(np.int32)
     both, loops2 = svsdf_amd.mesh_outline(V2, F2)
     assert loops2 == 2 and np.array_equal(both, b)
+    # the main loop is the one enclosing the largest AREA, not the one with the most vertices: a coarse 10 x 10 box
+    # (8 crossing points) next to the finely tessellated star (77)
+    V3 = V2.copy()
+    V3[len(V):, :2] = (V3[len(V):, :2] - np.array([20.0, 0.0])) * 10.0 + np.array([20.0, 0.0])
+    big, loops3 = svsdf_amd.mesh_outline(V3, F2)
+    assert loops3 == 2 and len(big) == 8 and big[:, 0].min() >= 20.0 - 1e-12
+    # ... and the TrajOptimizer mirror refuses to plan with one loop of several (the dropped part of the
+    # robot would collide unpenalised); the check runs before any device is touched
+    two = tmp_path / "two_bodies.obj"
+    with open(two, "w") as f:
+        for v in V3:
+            f.write("v %.9f %.9f %.9f\n" % tuple(v))
+        for t in F2:
+            f.write("f %d %d %d\n" % tuple(t + 1))
+    opt = svsdf_amd.TrajOptimizer()
+    opt.setParam(dict(inputdata=str(two)))
+    opt.setConditions(np.zeros((3, 3)), np.zeros((3, 3)), 2)
+    opt.setPoints(np.zeros((4, 3)))
+    with pytest.raises(svsdf_amd.SvsdfError, match="2 closed loops"):
+        opt._context()
     with pytest.raises(svsdf_amd.SvsdfError):
         svsdf_amd.mesh_outline_obj(tmp_path / "missing.obj")
     with pytest.raises(svsdf_amd.SvsdfError):
