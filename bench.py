@@ -380,16 +380,21 @@ def quick_run(name, P, steps, local_rank, generic=False):
         n_settle += 1
         if c.stats()["plan_settled"] and n_settle >= 2:
             break
-    c.eval_penalty(w["coeffs"], w["T"])
+    for _ in range(2):
+        c.eval_penalty(w["coeffs"], w["T"])
     torch.cuda.synchronize()
+    per = []
     t0 = time.perf_counter()
     for _ in range(steps):
-        c.eval_penalty(w["coeffs"], w["T"])
+        t1 = time.perf_counter()
+        c.eval_penalty(w["coeffs"], w["T"])      # (every entry point synchronises before it returns)
+        per.append(1e3 * (time.perf_counter() - t1))
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     st, pl = c.stats(), c.get_plan()
     out = {"workload": f"{name}: {w['shape']}, {len(w['T'])} pieces, {P} corridor points", "points_total": P, "steps": steps,
-           "ms_per_step": ms, "value": P / (ms * 1e-3), "unit": "query-points/s", "set_points_ms": set_ms,
+           "ms_per_step": ms, "ms_per_step_median": float(np.median(per)), "value": P / (ms * 1e-3), "unit": "query-points/s",
+           "set_points_ms": set_ms,
            "settle_evaluations": n_settle, "interior_fraction": st["interior_points"] / max(st["points"], 1),
            "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][pl["bound_mode"]], "batches": pl["batches"],
                     "lanes_per_query": pl["lanes_per_query"], "tail_iter": st["tail_iter"]}}
@@ -608,6 +613,7 @@ def main():
     if multi or devices is not None or ar_ms is not None:
         res["combine"] = {"ms_allreduce": ar_ms, "ms_combine_inprocess": combine_ms if a.inprocess else None,
                           "mode": ["host", "host", "rccl"][last["combine"]] if a.inprocess else "torch.distributed",
+                          "rccl_ranks": (r.ctx.group_info()["rccl_ranks"] if a.inprocess else (world if ar_ms is not None else 0)),
                           "note": "ms_allreduce: RCCL all-reduce of 19N+1 doubles alone (launch + sync, torchrun path); "
                                   "ms_combine_inprocess: host time from 'all devices done' to 'summed partial on the host'"}
     # release the headline workload before the sub-runs

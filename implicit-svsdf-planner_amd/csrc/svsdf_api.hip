@@ -199,6 +199,14 @@ struct svsdf_ctx {
   const double *h_partial = nullptr;  // where the last evaluation's summed partial lives on the host
   double combine_ms = 0.0, setup_ms = 0.0;
 
+  // svsdf_swept_outline: the last result, so that the documented query-then-fill protocol runs the extraction once
+  std::vector<double> ol_key, ol_xy;
+  std::vector<int> ol_loops;
+  svsdf_outline_stats ol_stats{};
+  bool ol_valid = false;
+  size_t lds_limit = 65536;         // dynamic LDS a block may ask for on this device
+  std::string launch_err;           // a launch that could not be made (LDS budget, shape not compiled); reported by join_batches
+
   // full-callback state (TrajOptimizer members BEO:44-60)
   svsdf_host::MincoS3 minco;
   std::vector<double> T, pgC, pgT, cm, gC, gradq, gradT, xlast;
@@ -318,20 +326,33 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
                   double cull_thresh = std::numeric_limits<double>::infinity()) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const long long lanes = std::max<long long>(max_queries * G, 64);
-  const size_t lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (ctx->poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
   // Every block stages the pose table + chunk bounds + trajectory into LDS (13 KB at 16 pieces x 2.5 s, 24 KB at 32):
   // with one wave per block that caps the CU at 160 KB / lds waves -- 6 at C3, half of what the kernel's 141 VGPRs
   // allow (3 waves per SIMD) -- so the block grows until LDS no longer binds (measured at C3: 10.7 -> 9.2 ms).
-  int blk = ctx->block;
+  // A Polygon's edges go in front of the tables while the whole block still fits the device's per-block LDS; a long
+  // trajectory (large pose table) falls back to the kernel variant that reads the edges from global memory.
   const size_t wlds = ladder_lds_bytes(G);   // per wave: the descent state of its 64 / G groups
-  if (!ctx->block_env) blk = ((lds + wlds) * 12 <= 160 * 1024) ? 64 : ((lds + 2 * wlds) * 6 <= 160 * 1024) ? 128 : 256;
-  const size_t lds_tables = (lds + 15) & ~(size_t)15;
-  const size_t lds_total = lds_tables + (size_t)(blk / 64) * wlds;
+  bool poly_lds = ctx->poly_lds;
+  size_t lds = 0, lds_total = 0;
+  int blk = ctx->block;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
+    blk = ctx->block;
+    if (!ctx->block_env) blk = ((lds + wlds) * 12 <= 160 * 1024) ? 64 : ((lds + 2 * wlds) * 6 <= 160 * 1024) ? 128 : 256;
+    lds_total = ((lds + 15) & ~(size_t)15) + (size_t)(blk / 64) * wlds;
+    if (lds_total <= ctx->lds_limit || !poly_lds) break;
+    poly_lds = false;
+  }
+  if (lds_total > ctx->lds_limit) {
+    if (ctx->launch_err.empty()) ctx->launch_err = "trajectory too long for the LDS pose table (" + std::to_string(lds_total) + " B of " + std::to_string(ctx->lds_limit) + " B per block)";
+    return;
+  }
   const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh};
-  (void)launch_k_solve(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds_total, st, a);
+  if (!launch_k_solve(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds_total, st, a) && ctx->launch_err.empty())
+    ctx->launch_err = "k_solve: shape not compiled into this build";
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -344,7 +365,16 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;   // k_round MODE: cheap / full / lazy bound
   const bool scans = mode != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
-  const size_t lds = (table_lds_doubles(ctx) + (ctx->poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
+  bool poly_lds = ctx->poly_lds;
+  size_t lds = (table_lds_doubles(ctx) + (poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
+  if (lds + 16384 > ctx->lds_limit && poly_lds) {   // (k_round's static tables: < 16 KB) edges from global memory instead
+    poly_lds = false;
+    lds = table_lds_doubles(ctx) * sizeof(double);
+  }
+  if (lds + 16384 > ctx->lds_limit) {
+    if (ctx->launch_err.empty()) ctx->launch_err = "trajectory too long for the LDS pose table (k_round)";
+    return;
+  }
   // late iterations hold few points and are latency-bound: request every sample there, which
   // avoids supplementary iterations at no cost in time
   // the seed bound of the scanning modes is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
@@ -363,7 +393,8 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
                       band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b, ctx->round_list};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  (void)launch_k_round(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, lp, mode, grid, lds, st, a);
+  if (!launch_k_round(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, lp, mode, grid, lds, st, a) && ctx->launch_err.empty())
+    ctx->launch_err = "k_round: shape not compiled into this build";
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -383,8 +414,18 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   long long pts = std::max(1, ctx->bcount[b]);
   if (ctx->have_prev_nactive && it0 <= ctx->prev_tail_iter && it0 < kMaxIter)
     pts = std::min<long long>(pts, ctx->prev_nactive[it0] / std::max(1, ctx->nbatch) * 5 / 4 + 64);
-  const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (ctx->poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
-  const size_t lds = lds_tables + (kTailBlock / 64) * kTailWaveLds;
+  bool poly_lds = ctx->poly_lds;
+  size_t lds = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
+    lds = lds_tables + (kTailBlock / 64) * kTailWaveLds;
+    if (lds <= ctx->lds_limit || !poly_lds) break;
+    poly_lds = false;
+  }
+  if (lds > ctx->lds_limit) {
+    if (ctx->launch_err.empty()) ctx->launch_err = "trajectory too long for the LDS pose table (k_tail)";
+    return;
+  }
   const long long per_block = (kTailBlock / 64) * 2;
   const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((pts + per_block - 1) / per_block, (long long)ctx->n_cu * 3));
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
@@ -393,7 +434,8 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
                      ctx->d_ctl + b, ctx->round_list, ctx->prune};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  (void)launch_k_tail(ctx->poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a);
+  if (!launch_k_tail(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a) && ctx->launch_err.empty())
+    ctx->launch_err = "k_tail: shape not compiled into this build";
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -547,6 +589,12 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
 
 
 int join_batches(svsdf_ctx *ctx) {
+  if (!ctx->launch_err.empty()) {   // a launch that could not be made: a clear error instead of a raw HIP launch failure
+    const std::string m = ctx->launch_err;
+    ctx->launch_err.clear();
+    for (int b = 0; b < ctx->nbatch; ++b) (void)hipStreamSynchronize(ctx->bstream[b]);
+    return fail(ctx, SVSDF_ERR_INVALID, m);
+  }
   for (int b = 0; b < ctx->nbatch; ++b) {
     HIPCHK(hipEventRecord(ctx->ev_done[b], ctx->bstream[b]));
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
@@ -822,7 +870,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
   if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; }
   // Batch count (large shards in the scanning modes; DESIGN.md "concurrent point batches").  Default: a RULE -- 3 batches in
-  // the full-scan mode, 2 in the lazy mode, from 400 k points per device, 1 otherwise (what the measurements of rounds 3 - 4
+  // a scanning bound mode from 400 k points per device, 1 otherwise (what the measurements of rounds 3 - 4 -- 1 / 2 / 3 / 4 at NS, C3, C4 --
   // chose on every box; with the main stream that is at most 4 streams, the HIP runtime's default number of hardware
   // queues) -- so that the plan is the same on every run and settled after the deciding evaluation.  svsdf_set_plan
   // (batches = -1) / SVSDF_BATCHES=measure ask for a measurement instead: after one evaluation that learns the launch
@@ -873,7 +921,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_tune = 1;
     const bool big = ctx->ub_full && ctx->P >= 400000;
     if (ctx->want_batches == 0) {
-      const int nb = big ? (ctx->ub_lazy ? 2 : 3) : 1;
+      const int nb = big ? 3 : 1;
       if (ctx->saved_nbatch > 0) ctx->saved_nbatch = nb;        // (serialised for profiling: takes effect when that ends)
       else if (nb != ctx->nbatch) rc = set_batches(ctx, nb);
     } else if (ctx->want_batches < 0 && big) {
@@ -1601,6 +1649,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n > 0) ctx->n_cu = n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && n > 0) ctx->lds_limit = (size_t)n;
   }
   if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
   if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
@@ -2167,8 +2216,30 @@ int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const doubl
   if (!ctx || !coeffs || !T || !n_verts || !n_loops) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: null argument");
   if (N < 1 || N > kMaxPieces || !(cell > 0.0) || !std::isfinite(cell) || !std::isfinite(margin))
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: N, cell or margin out of range");
+  if ((xy_out == nullptr) != (loop_sizes == nullptr))
+    return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: xy_out and loop_sizes must both be given (fill) or both be NULL (size query)");
   const svsdf_ctx *base = ctx->subs.empty() ? ctx : ctx->subs[0];
   if (base->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  // the size query and the fill that follows it carry the same arguments: the second call copies the first one's result
+  std::vector<double> key;
+  key.reserve(19 * (size_t)N + 3);
+  key.push_back((double)N); key.push_back(cell); key.push_back(margin);
+  key.insert(key.end(), coeffs, coeffs + 18 * (size_t)N);
+  key.insert(key.end(), T, T + N);
+  auto deliver = [&](const std::vector<double> &xy, const std::vector<int> &loops, const svsdf_outline_stats &st) -> int {
+    *n_verts = xy.size() / 2;
+    *n_loops = loops.size();
+    if (stats_out) *stats_out = st;
+    if (xy_out && loop_sizes) {
+      if (capacity_verts < xy.size() / 2 || capacity_loops < loops.size())
+        return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: output capacity too small (query with xy_out = NULL first)");
+      std::copy(xy.begin(), xy.end(), xy_out);
+      std::copy(loops.begin(), loops.end(), loop_sizes);
+    }
+    return SVSDF_OK;
+  };
+  if (ctx->ol_valid && ctx->ol_key.size() == key.size() && std::memcmp(ctx->ol_key.data(), key.data(), key.size() * sizeof(double)) == 0)
+    return deliver(ctx->ol_xy, ctx->ol_loops, ctx->ol_stats);
   // bounding box of the path (body origin), grown by the shape's bound radius: the swept volume lies inside
   double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
   for (int i = 0; i < N; ++i) {
@@ -2214,7 +2285,10 @@ int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const doubl
     rc = svsdf_shard_indices(tmp, idx.data());
     if (rc) return rc;
     val.assign(P, 0.0);
-    for (size_t k = 0; k < P; ++k) val[(size_t)idx[k]] = sdf[k];
+    for (size_t k = 0; k < P; ++k) {
+      if (!std::isfinite(sdf[k])) return SVSDF_ERR_NONFINITE;   // (a NaN would silently read as "outside")
+      val[(size_t)idx[k]] = sdf[k];
+    }
     return 0;
   };
   std::vector<double> xy;
@@ -2224,25 +2298,23 @@ int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const doubl
   const std::string tmp_err = rc ? svsdf_last_error_string(tmp) : "";
   svsdf_destroy(tmp);
   if (rc) return fail(ctx, rc > 0 ? rc : SVSDF_ERR_INVALID, "svsdf_swept_outline: evaluation failed: " + tmp_err);
-  *n_verts = xy.size() / 2;
-  *n_loops = loops.size();
-  if (stats_out) {
-    stats_out->nodes_evaluated = st.nodes_evaluated; stats_out->dense_nodes = st.dense_nodes;
-    stats_out->cells_marched = st.cells_marched; stats_out->batches = st.batches; stats_out->open_chains = st.open_chains;
-  }
-  if (xy_out && loop_sizes) {
-    if (capacity_verts < xy.size() / 2 || capacity_loops < loops.size())
-      return fail(ctx, SVSDF_ERR_INVALID, "svsdf_swept_outline: output capacity too small (query with xy_out = NULL first)");
-    std::copy(xy.begin(), xy.end(), xy_out);
-    std::copy(loops.begin(), loops.end(), loop_sizes);
-  }
-  return SVSDF_OK;
+  svsdf_outline_stats so{};
+  so.nodes_evaluated = st.nodes_evaluated; so.dense_nodes = st.dense_nodes;
+  so.cells_marched = st.cells_marched; so.batches = st.batches; so.open_chains = st.open_chains;
+  ctx->ol_key.swap(key);
+  ctx->ol_xy = xy;
+  ctx->ol_loops = loops;
+  ctx->ol_stats = so;
+  ctx->ol_valid = true;
+  return deliver(ctx->ol_xy, ctx->ol_loops, ctx->ol_stats);
 }
 
 int svsdf_outline_extrude(const double *xy, const int *loop_sizes, size_t n_loops, double z0, double z1, int caps,
                           double *V_out, size_t capacity_verts, size_t *n_verts, int *F_out, size_t capacity_tris,
                           size_t *n_tris) {
-  if (!xy || !loop_sizes || !n_verts || !n_tris || !std::isfinite(z0) || !std::isfinite(z1)) return SVSDF_ERR_INVALID;
+  if (!n_verts || !n_tris || !std::isfinite(z0) || !std::isfinite(z1)) return SVSDF_ERR_INVALID;
+  if (n_loops == 0) { *n_verts = 0; *n_tris = 0; return SVSDF_OK; }   // an empty outline extrudes to an empty surface
+  if (!xy || !loop_sizes) return SVSDF_ERR_INVALID;
   for (size_t l = 0; l < n_loops; ++l)
     if (loop_sizes[l] < 3) return SVSDF_ERR_INVALID;
   std::vector<double> V;

@@ -65,6 +65,7 @@ def lib():
     L.orc_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.orc_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
     L.orc_set_modes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_set_trig_perturb.argtypes = [C.c_void_p, C.c_ulonglong]
     L.orc_cost_function.restype = C.c_double
     L.orc_cost_function.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _dp, C.c_int, _dp]
     L.orc_minco_coeffs.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _dp]
@@ -205,6 +206,10 @@ class Oracle:
     def set_trig_mode(self, mode):
         """1: sin/cos/atan2 by the ROCm device library's algorithms (diagnostic); 0: libm (oracle of record)."""
         self.L.orc_set_trig_mode(self.ctx, int(mode))
+
+    def set_trig_perturb(self, seed):
+        """Third oracle of the sensitivity bracket: libm sin/cos/atan2 moved by -1/0/+1 ulp (hash of argument and seed)."""
+        self.L.orc_set_trig_perturb(self.ctx, int(seed))
 
     def set_modes(self, trig_mode, cum_locate):
         """The two diagnostic switches separately: trig_mode 1 = device-library sin/cos/atan2; cum_locate 1 = piece-local

@@ -24,7 +24,9 @@ struct orc_ctx {
   double head[9], tail[9]; /* 3x3 column-major: col0 = pos, col1 = vel, col2 = acc */
   orc_counters cnt;
   int have_duration;
-  int trig_mode; /* 0: libm sin/cos/atan2 (the reference's arithmetic); 1: the ROCm device library's algorithms */
+  int trig_mode; /* 0: libm sin/cos/atan2 (the reference's arithmetic); 1: the ROCm device library's algorithms;
+                    2: libm results moved by -1 / 0 / +1 ulp, pseudo-randomly per argument (orc_set_trig_perturb) */
+  unsigned long long trig_seed;
 };
 
 /* thread-local work counters, folded into ctx->cnt by the entry points */
@@ -568,12 +570,38 @@ static double dev_atan2(double y, double x) {
   if (isnan(x) || isnan(y)) t = NAN;
   return copysign(t, y);
 }
+/* trig_mode 2: "some other libm".  glibc's sin / cos / atan2 are accurate to < 1 ulp but not correctly rounded; another
+ * build of the reference (another libm, another compiler's vector math) may return either neighbour.  The result is
+ * moved by k in {-1, 0, +1} ulp, k a hash of (argument bits, seed): deterministic per argument, so the oracle stays a
+ * function.  Sensitivity bracket of tools/fuzz_parity.py: how far does the reference's own answer move under a <= 1 ulp
+ * change of these three functions? */
+static inline double ulp_nudge(double v, unsigned long long key) {
+  key ^= key >> 33; key *= 0xff51afd7ed558ccdULL; key ^= key >> 33; key *= 0xc4ceb9fe1a85ec53ULL; key ^= key >> 33;
+  const int k = (int)(key % 3ULL) - 1;
+  if (k == 0 || !isfinite(v)) return v;
+  return nextafter(v, k > 0 ? INFINITY : -INFINITY);
+}
+static inline unsigned long long dbits(double a) { unsigned long long u; memcpy(&u, &a, 8); return u; }
 static inline void trig_sincos(const orc_ctx *ctx, double a, double *sn, double *cs) {
-  if (ctx->trig_mode) dev_sincos(a, sn, cs);
-  else { *sn = sin(a); *cs = cos(a); }
+  if (ctx->trig_mode == 1) dev_sincos(a, sn, cs);
+  else {
+    *sn = sin(a); *cs = cos(a);
+    if (ctx->trig_mode == 2) {
+      *sn = ulp_nudge(*sn, dbits(a) ^ ctx->trig_seed);
+      *cs = ulp_nudge(*cs, dbits(a) ^ (ctx->trig_seed * 0x9e3779b97f4a7c15ULL + 1ULL));
+    }
+  }
 }
 static inline double trig_atan2(const orc_ctx *ctx, double y, double x) {
-  return ctx->trig_mode ? dev_atan2(y, x) : atan2(y, x);
+  if (ctx->trig_mode == 1) return dev_atan2(y, x);
+  const double v = atan2(y, x);
+  return ctx->trig_mode == 2 ? ulp_nudge(v, dbits(y) ^ (dbits(x) * 0x9e3779b97f4a7c15ULL) ^ ctx->trig_seed) : v;
+}
+void orc_set_trig_perturb(orc_ctx *ctx, unsigned long long seed) {
+  /* libm trig moved by <= 1 ulp (seeded), the reference's piece location: a third oracle for the sensitivity bracket */
+  ctx->trig_mode = 2;
+  ctx->trig_seed = seed * 0x9e3779b97f4a7c15ULL + 0x632be59bd9b4e019ULL;
+  ctx->traj.cum_locate = 0;
 }
 void orc_set_modes(orc_ctx *ctx, int trig_mode, int cum_locate) {
   /* the two diagnostic switches separately: device-library trig (1) and cumulative piece location (1) */

@@ -147,6 +147,9 @@ size_t orc_gd_trace_count(void);
  * operation for operation.  Mode 0 (default) is the oracle of record. */
 void orc_set_trig_mode(orc_ctx *ctx, int mode);
 void orc_set_modes(orc_ctx *ctx, int trig_mode, int cum_locate);
+/* third oracle of the fuzz gate's sensitivity bracket: libm sin / cos / atan2 results moved by -1 / 0 / +1 ulp
+ * (a deterministic hash of the argument and `seed`), the reference's piece location */
+void orc_set_trig_perturb(orc_ctx *ctx, unsigned long long seed);
 
 /* ---- MINCO S3NU + full callback (a14) --------------------------------------- */
 /* x = [tau_0..tau_{N-1}, q_0 (x,y,yaw), ..., q_{N-2}], n = N + 3(N-1). Returns cost,

@@ -216,6 +216,23 @@ def test_bench_gpus_n_drives_n_devices_by_itself(built):
         r = _bench(["--gpus", "2", "--devices", "0,0", "--points", "400000", "--steps", "2", "--warmup", "1", "--no-extras"])
     assert r["n_gpus"] == 2 and r["config"]["points_per_gpu"] == 200000 and r["scaling"] == "strong"
     assert r["config"]["shape"] == "sdHeart" and r["combine"]["ms_combine_inprocess"] is not None
+    # both combines are timed in the same run; the RCCL communicator must hold one rank per GPU -- read
+    # back from the communicator itself -- or the line must say why RCCL was not run (two stripes on one GPU)
+    ab = r["combine_ab"]
+    assert ab["host_ms_per_step"] > 0
+    if torch.cuda.device_count() >= 2:
+        assert ab["rccl_ranks"] == r["n_gpus"] == 2 and ab["rccl_ms_per_step"] > 0
+    else:
+        assert ab["rccl_ranks"] == 0 and ab["rccl_ms_per_step"] is None and "one rank per distinct GPU" in ab["rccl_note"]
+
+
+@pytest.mark.gpu
+def test_bench_one_device_rccl_reports_its_rank_count(built):
+    """The RCCL combine as a 1-rank communicator (all a 1-GPU box can form): the bench line carries the rank count the
+    communicator itself reports (ncclCommCount), so an N-GPU line can be checked against n_gpus."""
+    r = _bench(["--gpus", "1", "--inprocess", "--combine", "rccl", "--config", "C2", "--steps", "2", "--warmup", "1",
+                "--no-extras", "--no-cpu-baseline"])
+    assert r["combine"]["mode"] == "rccl" and r["combine"]["rccl_ranks"] == 1
 
 
 @pytest.mark.gpu

@@ -1,12 +1,17 @@
 """Differential fuzzing (GPU box): random shapes / shape offsets / trajectories / points, HIP path vs the oracle.
 Prints every case outside the gates (cost 1e-7 rel, gradient 1e-5 rel) or with > 1 % basin flips.
 
-A case outside the gates is then CLASSIFIED: the oracle is run a second time with the ROCm device library's sin / cos /
-atan2 in place of glibc's (orc.set_modes(1, 0): the ONLY arithmetic the HIP path does not share with the oracle of
-record) and its deviation from the oracle of record is measured with the same metrics.  If oracle-vs-oracle shows the
-same deviation as HIP-vs-oracle to 1e-3 relative on every violated metric, the case is `libm_explained` (a plateau of
-SDF(t): the reference's own result would change with the libm build, tests/test_plateau_sensitivity.py); anything else is
-`unexplained` and is what tests/test_gpu_parity.py::test_differential_fuzz fails on.
+A case outside the gates is then CLASSIFIED by a SENSITIVITY BRACKET of the oracle against itself (round 4; the round-3
+rule -- "the oracle with the device library's trig shows the same deviation" -- is a tautology once the HIP path equals
+that oracle bit for bit).  The oracle of record (glibc sin / cos / atan2) is re-run with its three trig functions moved
+by -1 / 0 / +1 ulp per argument (orc.set_trig_perturb, three seeds): another libm the reference could have been built
+with.  These runs know nothing of the ROCm device library.  A case is `libm_explained` only if, on EVERY violated metric,
+the largest deviation among the perturbed oracles (from the oracle of record) is at least BRACKET x the HIP deviation
+(BRACKET = 0.25: on a plateau of SDF(t) the size of the jump depends on which basin the argmin lands in, so the
+deviations scatter, but a <= 1 ulp change of the trig must be able to move the reference's OWN answer by a comparable
+amount) and the HIP deviation stays under an absolute ceiling (cost 1e-2, gradients 0.2, flips 10 %).  Anything else is
+`unexplained` and is what tests/test_gpu_parity.py::test_differential_fuzz fails on.  The device-trig oracle's deviation
+is still printed (it equals the HIP deviation when the kernels are right).
 usage: fuzz_parity.py [cases] [seed]   env FUZZ_DEGENERATE=0|1 (default 1), FUZZ_DEVICE_TRIG, FUZZ_PIECE_TIME"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,21 +92,29 @@ for case in range(ncase):
         bad += 1
         verdict = "n/a"
         if not devtrig and np.isfinite(cost):
-            # oracle vs oracle: glibc trig (of record) against the device library's trig, same metrics
-            o.set_modes(1, 0 if exact_time else 1)
-            c1, gT1, gC1, _, ts1, _ = o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True)
+            def dev_of(run):   # deviation of an oracle run from the oracle of record, same metrics
+                c1, gT1, gC1, _, ts1, _ = run
+                dc = abs(c1 - ocost) / max(abs(ocost), 1e-300) if ocost != 0 else abs(c1)
+                dC, dT = (rel(gC1, ogC), rel(gT1, ogT)) if ocost != 0 else (float(np.abs(gC1).max()), float(np.abs(gT1).max()))
+                return dc, dC, dT, float((np.abs(ts1 - ots) > 1e-6).mean())
+            o.set_modes(1, 0 if exact_time else 1)           # the device library's trig (what the HIP path computes with)
+            d_c, d_C, d_T, d_f = dev_of(o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True))
+            br = [0.0, 0.0, 0.0, 0.0]                         # bracket: libm results moved by <= 1 ulp, three seeds
+            for ps in (1, 2, 3):
+                o.set_trig_perturb(1000 * seed0 + 10 * case + ps)
+                br = [max(a, b) for a, b in zip(br, dev_of(o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True)))]
             o.set_modes(0, 0)
-            d_c = abs(c1 - ocost) / max(abs(ocost), 1e-300) if ocost != 0 else abs(c1)
-            d_C, d_T = (rel(gC1, ogC), rel(gT1, ogT)) if ocost != 0 else (float(np.abs(gC1).max()), float(np.abs(gT1).max()))
-            d_f = float((np.abs(ts1 - ots) > 1e-6).mean())
-            same = lambda a, b: abs(a - b) <= 1e-3 * max(abs(b), 1e-300)
-            ok = ((rc <= 1e-7 or same(rc, d_c)) and (rC <= 1e-5 or same(rC, d_C)) and (rT <= 1e-5 or same(rT, d_T)) and
-                  (flips <= 0.01 or abs(flips - d_f) <= 1e-3 * max(d_f, 1e-300) + 0.5 / P))
+            BR = 0.25
+            ok = ((rc <= 1e-7 or br[0] >= BR * rc) and (rC <= 1e-5 or br[1] >= BR * rC) and (rT <= 1e-5 or br[2] >= BR * rT) and
+                  (flips <= 0.01 or br[3] + 0.5 / P >= BR * flips) and rc <= 1e-2 and rC <= 0.2 and rT <= 0.2 and flips <= 0.10)
             verdict = "libm_explained" if ok else "UNEXPLAINED"
             worst["libm_explained" if ok else "unexplained"] += 1
             if not ok:
                 worst["worst_unexplained_gC"] = max(worst["worst_unexplained_gC"], rC)
-            verdict += f" (oracle glibc vs oracle device-trig: cost {d_c:.2e} gC {d_C:.2e} gT {d_T:.2e} flips {d_f:.3f})"
+            ratios = [b / max(h, 1e-300) for b, h in zip(br, (rc, rC, rT, max(flips, 0.5 / P)))]
+            worst["min_bracket_ratio"] = min(worst.get("min_bracket_ratio", 1e300), min(r_ for r_, v, g_ in zip(ratios, (rc, rC, rT, flips), (1e-7, 1e-5, 1e-5, 0.01)) if v > g_) if ok else 0.0)
+            verdict += (f" (1-ulp bracket of the oracle, 3 seeds: cost {br[0]:.2e} gC {br[1]:.2e} gT {br[2]:.2e} flips {br[3]:.3f};"
+                        f" device-trig oracle: cost {d_c:.2e} gC {d_C:.2e} gT {d_T:.2e} flips {d_f:.3f})")
         print(f"CASE {case} seed {seed0} shape {shape} pp {np.round(pp, 3)} N {N} kind {kind} sh {sh:.3f}: cost {cost:.9g} vs {ocost:.9g} "
               f"(rel {rc:.2e}) gC {rC:.2e} gT {rT:.2e} flips {flips:.3f} interior {int((osdf <= 0).sum())} -> {verdict}", flush=True)
     ctx.close()
