@@ -3,9 +3,11 @@
 hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU
 box with the gpurun snapshot.
 
-Five translation units, compiled in parallel: csrc/svsdf_api.hip (C ABI, host logic, the shape-independent kernels)
-and csrc/svsdf_shape_slice.hip four times (-DSVSDF_SLICE=0..3: the kernels specialised per shape id, shapes with
-id % 4 == slice).  One TU took 140 s; the parallel build takes ~50 s on 8 cores.
+Eight translation units, compiled in parallel and incrementally: the host layer in four (csrc/svsdf_pipeline.hip: one
+device's pipeline + the shape-independent kernels; svsdf_group.hip: in-process multi-GPU; svsdf_capi.hip: the hot
+path's C ABI; svsdf_extras.hip: front end, map / mesh / outline helpers, L-BFGS driver) and
+csrc/svsdf_shape_slice.hip four times (-DSVSDF_SLICE=0..3: the kernels specialised per shape id, shapes with
+id % 4 == slice).  A host-side edit recompiles one small unit; a kernel edit the pipeline unit and the slices.
 """
 import glob
 import os
@@ -49,7 +51,7 @@ def build(force=False, verbose=False, out=OUT, extra_flags=(), tag=""):
         return out
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    units = [("api" + tag, os.path.join(CSRC, "svsdf_api.hip"), [])]
+    units = [(h + tag, os.path.join(CSRC, f"svsdf_{h}.hip"), []) for h in ("pipeline", "group", "capi", "extras")]
     units += [(f"slice{k}{tag}", os.path.join(CSRC, "svsdf_shape_slice.hip"), [f"-DSVSDF_SLICE={k}"]) for k in range(NSLICES)]
     procs = []
     objs_kept = []
@@ -57,7 +59,7 @@ def build(force=False, verbose=False, out=OUT, extra_flags=(), tag=""):
     for name, src, defs in units:
         obj = os.path.join(OBJDIR, name + ".o")
         # incremental: an object whose sources (and flags) did not change since it was compiled is kept -- a host-side
-        # edit of svsdf_api.hip then costs one translation unit instead of five
+        # edit then costs one small translation unit
         deps = SLICE_DEPS if name.startswith("slice") else DEPS
         stamp = obj + ".flags"
         if (not force and not tag and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flags_key and

@@ -85,7 +85,7 @@ struct BatchCtl {
   int n_seed[kMaxIter + 2];       // [i] = circle samples emitted in iteration i (statistics)
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
   int nonfinite;
-  int pad;
+  int n_int;                      // ctl[0] only: interior points of the whole shard so far = next compact interior index
   // work counters (statistics), added to by every wave at the end of a launch: one address takes ~80 M atomics / s
   // (tools/experiments/coh_latency.hip), a full grid of waves ending together would queue up behind four words of one
   // cache line -- the waves spread over kStatSlots lines, k_finish adds them up
@@ -248,7 +248,7 @@ __device__ __forceinline__ void sincos_exact(double a, double *sn, double *cs) {
   *cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
 }
 
-#ifdef SVSDF_API_TU   // shape-independent kernel: compiled once, by svsdf_api.hip
+#ifdef SVSDF_API_TU   // shape-independent kernel: compiled once, by svsdf_pipeline.hip
 // mismatch counter for sincos_exact vs the library sincos (diagnostics / test only)
 __global__ void k_sincos_check(double lo, double hi, int n, unsigned long long *mism) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,7 +431,7 @@ __device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp,
   return sdf_from_pose<SHAPE>(sp, p, px, py);
 }
 
-#ifdef SVSDF_API_TU   // shape-independent kernel: compiled once, by svsdf_api.hip
+#ifdef SVSDF_API_TU   // shape-independent kernel: compiled once, by svsdf_pipeline.hip
 // ---------------------------------------------------------------------------------------------
 // k_prep: one block.  in = [coeffs (6N x 3 column-major) | T (N) | tk (K)] as uploaded.
 // Also clears the per-batch control blocks for this evaluation.
@@ -447,6 +447,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     for (int r = 0; r < kMaxIter + 2; ++r) { c.n_active[r] = 0; c.n_solve[r] = 0; c.n_seed[r] = 0; }
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
     c.nonfinite = 0;
+    c.n_int = 0;
   }
   for (int i = threadIdx.x; i < nbatch * kStatSlots; i += blockDim.x) {
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
@@ -658,9 +659,13 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
   best_d = 1e9;   // min_dis initial value (SWM:545)
   best_k = 0x7fffffff;
   culled = false;
+  // Every lane keeps the lexicographic minimum (value, index) of the poses IT evaluated; after a chunk only the VALUE is
+  // reduced over the group (the pruning tests need nothing else: 3 instructions per butterfly step instead of 9), the
+  // (value, index) pairs meet once, at the end of the scan (finish_scan).  Same minimum, same earliest index.
+  double d_lane = 1e300;
+  int k_lane = 0x7fffffff;
   auto eval_chunk = [&](int c) {
     double d_loc = 1e300;
-    int k_loc = 0x7fffffff;
     constexpr int GS = (G < kChunk) ? G : kChunk;
 #pragma unroll
     for (int m = 0; m < kChunk / GS; ++m) {
@@ -670,11 +675,21 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
         const Pose p = pose[k];
         const double d = sdf_from_pose<SHAPE>(sp, p, px, py);
         ++n_scan;
-        if (d < d_loc) { d_loc = d; k_loc = k; }  // k increases with m: earliest kept on ties
+        if (d < d_loc) d_loc = d;
+        if (d < d_lane || (d == d_lane && k < k_lane)) { d_lane = d; k_lane = k; }
       }
     }
-    Grp<G>::min_dk(d_loc, k_loc);
-    if (d_loc < best_d || (d_loc == best_d && k_loc < best_k)) { best_d = d_loc; best_k = k_loc; }
+    if constexpr (G >= 2) d_loc = dmin(d_loc, Grp<G>::template xchg<0>(d_loc));
+    if constexpr (G >= 4) d_loc = dmin(d_loc, Grp<G>::template xchg<1>(d_loc));
+    if constexpr (G >= 8) d_loc = dmin(d_loc, Grp<G>::template xchg<2>(d_loc));
+    if constexpr (G >= 16) d_loc = dmin(d_loc, Grp<G>::template xchg<3>(d_loc));
+    if constexpr (G >= 32) d_loc = dmin(d_loc, Grp<G>::template xchg<4>(d_loc));
+    if (d_loc < best_d) best_d = d_loc;
+  };
+  auto finish_scan = [&]() {
+    Grp<G>::min_dk(d_lane, k_lane);
+    // (lexicographic minimum with the initial (1e9, none), like the sequential update it replaces)
+    if (d_lane < 1e9 || (d_lane == 1e9 && k_lane != 0x7fffffff)) { best_d = d_lane; best_k = k_lane; }
   };
   if constexpr (LITE) {
     const int nl = (ncl < 0) ? nch : ncl;
@@ -711,8 +726,10 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
       eval_chunk(__shfl(cc, first, G));
       j = j + first + 1;
     }
+    finish_scan();
   } else if (!prune) {
     for (int c = 0; c < nch; ++c) eval_chunk(c);
+    finish_scan();
   } else {
     // 1. the chunk with the smallest lower bound gives the first upper bound
     double lb_loc = 1e300, lbc_loc = 1e300;
@@ -752,6 +769,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
       eval_chunk(c + first);
       c = c + first + 1;
     }
+    if (!culled) finish_scan();
   }
 }
 
@@ -1165,13 +1183,22 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
 }
 
 // ---------------------------------------------------------------------------------------------
-// GSIP state (getTrueSDFofSweptVolume SWM:916-1018), one entry per interior point; every array
-// is indexed by (batch start + interior index within the batch).
+// GSIP state (getTrueSDFofSweptVolume SWM:916-1018), one entry per interior point.  Round 4: the per-interior-point
+// arrays and the sample arrays are indexed by a COMPACT interior index ia over the whole shard (k_classify hands them
+// out from one counter, BatchCtl::n_int of batch 0) and sized by the interior capacity `icap`, not by the point count;
+// a batch's active lists hold ia.  An evaluation that finds more interior points than icap drops the surplus, reports
+// the count, and the host grows the arrays and repeats it (svsdf_pipeline.hip, evaluate_points).
 // ---------------------------------------------------------------------------------------------
 #ifndef SVSDF_LAZY_REPS
 #define SVSDF_LAZY_REPS 2   // scan passes of the lazy bound mode: the band, then its extension (a third changes nothing)
 #endif
 enum : int { kPhaseEval = 0, kPhaseSupp = 1, kPhaseNew = 2 };
+#ifndef SVSDF_LEAN_HANDOFF
+#define SVSDF_LEAN_HANDOFF 0   // 1: only requested GSIP samples get a record (position, angle); 0: every emitted sample.  Measured
+                               // round 4 (profiles/r04_handoff_ab.txt): the lean form writes a third of the bytes and is 1.5 % (C3)
+                               // to 5 % (NS) SLOWER -- its stores wait for the selection at the end of a point's chain instead of
+                               // running under the scans, and HBM is at 2 % of its peak either way.  Kept as a build option.
+#endif
 // Sample slot of (interior point ia, sample j): slot-major [j * stride + ia] (stride = points in the shard).  A point-major
 // layout [ia * 24 + j] -- the samples of a point in one or two cache lines for k_round's lanes -- was measured in round 3
 // (tools/traffic_ab.sh, -DSVSDF_POINT_MAJOR): same evaluation time, but MORE HBM traffic (k_solve's reads of the selected
@@ -1190,11 +1217,15 @@ struct GsipState {
   int *iter;        // 1..9
   int *nsamp;       // samples emitted for the current round
   int *phase;       // kPhaseNew: a round has to be opened; kPhaseEval / kPhaseSupp: samples are out
+  unsigned *req;    // samples of the current round requested so far (bit j <-> sample j): the only ones that carry a record
   int *list[2];     // ping-pong compacted lists of still-active interior indices
   int *solve;       // sample slots to solve in the current iteration (capacity kMaxSlots per point)
-  // sample slots: sample_slot(stride, batch start + a, j) = [j * stride + batch start + a]
+  // sample slots: sample_slot(stride, batch start + a, j) = [j * stride + batch start + a].  Every emitted sample has its
+  // upper bound sq_ub and (scanning modes) seed index sq_k; only REQUESTED samples (gs.req) get a record -- position,
+  // angle -- and, from the solve, value and time: 12 B per emitted sample + 40 B per requested one instead of 52 B per
+  // emitted one (round 4, SVSDF_LEAN_HANDOFF)
   double *sqx, *sqy, *sqth, *sq_ub, *sq_sdf, *sq_t;
-  int *sq_k;        // layer-1 seed index of the sample (full-scan mode: sq_ub is then the seed value)
+  int *sq_k;        // layer-1 seed index of the sample (scanning modes: sq_ub is then the seed value); -1: none, the solve scans
 };
 
 // Per main point after the first solve: exterior -> FD gradient (getGradPrelAtTimeStamp,
@@ -1205,15 +1236,21 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
            const double *__restrict__ py_, const double *__restrict__ sdf_,
            const double *__restrict__ t_, double *__restrict__ res_sdf,
            double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
-           GsipState gs, BatchCtl *__restrict__ ctl) {
+           GsipState gs, BatchCtl *__restrict__ ctl, int *__restrict__ n_int, int icap) {
   extern __shared__ double classify_lds[];
   const TrajL tr = stage_traj(trg, classify_lds);
   const int start = ctl->start, count = ctl->count;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
-    const int i = start + e;
+  const int lane = (int)(threadIdx.x & 63);
+  // (wave-uniform trip count: the interior lanes of a wave take their indices together, below)
+  for (int e0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u); e0 < count; e0 += gridDim.x * blockDim.x) {
+    const int e = e0 + lane;
+    const bool in_range = e < count;
+    const int i = start + (in_range ? e : 0);
     const double px = px_[i], py = py_[i];
     const double sdf = sdf_[i], ts = t_[i];
-    if (sdf > 0) {  // outside case (SWM:921-924)
+    const bool inter = in_range && !(sdf > 0);
+    double vx = 0.0, vy = 0.0, w = 0.0;
+    if (in_range && sdf > 0) {  // outside case (SWM:921-924)
       int piece = 0;
       const Pose p = pose_at(tr, ts, piece);
       const double dx = px - p.x, dy = py - p.y;
@@ -1222,42 +1259,62 @@ k_classify(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__rest
       double gx, gy;
       shape_grad<SHAPE>(sp, rx, ry, gx, gy);
       res_sdf[i] = sdf; res_t[i] = ts; res_gx[i] = gx; res_gy[i] = gy;
-      continue;
-    }
-    // interior: velocity at t* with the low-speed rescans (SWM:929-954)
-    double sl;
-    int piece = locate_local(tr, ts, 0, sl);
-    double vx, vy, w;
-    piece_vel(tr.c + piece * 18, sl, vx, vy, w);
-    if (sqrt(vx * vx + vy * vy + w * w) < 0.01) {
-      if (ts < 0.1) {
-        for (double t_scan = ts; t_scan <= tr.dur; t_scan += 0.1) {
-          piece = locate_local(tr, t_scan, piece, sl);
-          piece_vel(tr.c + piece * 18, sl, vx, vy, w);
-          if (sqrt(vx * vx + vy * vy + w * w) >= 0.01) break;
-        }
-      } else if (ts > tr.dur - 0.1) {
-        for (double t_scan = ts; t_scan >= 0; t_scan -= 0.1) {
-          piece = locate_local(tr, t_scan, piece, sl);
-          piece_vel(tr.c + piece * 18, sl, vx, vy, w);
-          if (sqrt(vx * vx + vy * vy + w * w) >= 0.01) break;
+    } else if (inter) {
+      // interior: velocity at t* with the low-speed rescans (SWM:929-954)
+      double sl;
+      int piece = locate_local(tr, ts, 0, sl);
+      piece_vel(tr.c + piece * 18, sl, vx, vy, w);
+      if (sqrt(vx * vx + vy * vy + w * w) < 0.01) {
+        if (ts < 0.1) {
+          for (double t_scan = ts; t_scan <= tr.dur; t_scan += 0.1) {
+            piece = locate_local(tr, t_scan, piece, sl);
+            piece_vel(tr.c + piece * 18, sl, vx, vy, w);
+            if (sqrt(vx * vx + vy * vy + w * w) >= 0.01) break;
+          }
+        } else if (ts > tr.dur - 0.1) {
+          for (double t_scan = ts; t_scan >= 0; t_scan -= 0.1) {
+            piece = locate_local(tr, t_scan, piece, sl);
+            piece_vel(tr.c + piece * 18, sl, vx, vy, w);
+            if (sqrt(vx * vx + vy * vy + w * w) >= 0.01) break;
+          }
         }
       }
     }
-    const int a = atomicAdd(&ctl->n_active[0], 1);
-    const size_t ia = (size_t)start + a;
-    // SampleSet2D::initSet (SWM:73-103)
-    double theta0 = atan2(vx, -vy);
-    if (theta0 < 0) theta0 += 2 * kPI;
-    gs.pt[ia] = i;
-    gs.r[ia] = 10;               // r0 (SWM:927)
-    gs.theta0[ia] = theta0;
-    gs.theta_res[ia] = kPI + 0.1;
-    gs.iter[ia] = 1;
-    gs.nsamp[ia] = 0;
-    gs.phase[ia] = kPhaseNew;
-    gs.list[0][ia] = a;
-    res_t[i] = ts;  // real_t_star fallback
+    // compact interior indices, one block of consecutive ones per wave (one atomic for the wave instead of one per
+    // point; neighbouring points keep neighbouring entries in the interior-sized arrays)
+    const unsigned long long mi = __ballot(inter);
+    if (mi == 0ull) continue;   // wave-uniform
+    const int leader = __ffsll((long long)mi) - 1;
+    int base_i = 0;
+    if (lane == leader) base_i = atomicAdd(n_int, __popcll(mi));
+    base_i = __shfl(base_i, leader, 64);
+    const int ia_ = base_i + __popcll(mi & ((1ull << lane) - 1ull));
+    const bool kept = inter && ia_ < icap;
+    if (inter && !kept) {   // no room: dropped (reads as inactive); the host sees n_int > icap, grows the arrays and repeats
+      res_sdf[i] = 1e300; res_t[i] = ts; res_gx[i] = 0.0; res_gy[i] = 0.0;
+    }
+    const unsigned long long mk = __ballot(kept);
+    if (mk == 0ull) continue;
+    const int leader2 = __ffsll((long long)mk) - 1;
+    int base_a = 0;
+    if (lane == leader2) base_a = atomicAdd(&ctl->n_active[0], __popcll(mk));
+    base_a = __shfl(base_a, leader2, 64);
+    if (kept) {
+      const int a = base_a + __popcll(mk & ((1ull << lane) - 1ull));
+      const size_t ia = (size_t)ia_;
+      // SampleSet2D::initSet (SWM:73-103)
+      double theta0 = atan2(vx, -vy);
+      if (theta0 < 0) theta0 += 2 * kPI;
+      gs.pt[ia] = i;
+      gs.r[ia] = 10;               // r0 (SWM:927)
+      gs.theta0[ia] = theta0;
+      gs.theta_res[ia] = kPI + 0.1;
+      gs.iter[ia] = 1;
+      gs.nsamp[ia] = 0;
+      gs.phase[ia] = kPhaseNew;
+      gs.list[0][start + a] = ia_;
+      res_t[i] = ts;  // real_t_star fallback
+    }
   }
 }
 
@@ -1315,7 +1372,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
   size_t ia = 0;
   bool open = false;
   double cx = 0.0, cy = 0.0, r = 0.0, theta0 = 0.0, theta_res = 0.0;
-    ia = (size_t)start + a;
+    ia = (size_t)a;   // (a: compact interior index of the point; `start` is the batch's offset in the point arrays)
     i = gs.pt[ia];
     cx = px_[i]; cy = py_[i];
     r = gs.r[ia]; theta0 = gs.theta0[ia]; theta_res = gs.theta_res[ia];
@@ -1323,13 +1380,14 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
     if (!open) {
       // ---- close the round: max over the solved samples, first index wins ties (strict >)
       const int n = gs.nsamp[ia];
+      const unsigned req = gs.req[ia];   // samples requested so far: the solved ones
       double g_mine[NP];
       double g = kUnsolved;
       int idx = 0x7fffffff;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        g_mine[ps] = (j < n) ? gs.sq_sdf[sample_slot(stride, ia, j)] : kUnsolved;
+        g_mine[ps] = (j < n && (!SVSDF_LEAN_HANDOFF || ((req >> j) & 1u))) ? gs.sq_sdf[sample_slot(stride, ia, j)] : kUnsolved;
         if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
       }
       {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
@@ -1352,9 +1410,31 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        list_me[ps] = (j < n) && g_mine[ps] == kUnsolved && gs.sq_ub[sample_slot(stride, ia, j)] >= max_g;
+        list_me[ps] = (j < n) && (SVSDF_LEAN_HANDOFF ? !((req >> j) & 1u) : (g_mine[ps] == kUnsolved)) && gs.sq_ub[sample_slot(stride, ia, j)] >= max_g;
         mlist[ps] = ballot_g(list_me[ps]);
         any = any || (mlist[ps] != 0u);
+      }
+      if (any && SVSDF_LEAN_HANDOFF) {
+        // (rare) the newly requested samples get their record now: position and angle recomputed exactly as the opening
+        // of the round computed them (same operations on the same operands); no scan seed -- the solve scans itself
+        double theta = theta0;
+        for (int q = 0; q < l; ++q) theta += theta_res;
+        unsigned nreq = req;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+          if (list_me[ps]) {
+            const size_t s = sample_slot(stride, ia, l + LP * ps);
+            gs.sqx[s] = cx + 1.0 * r * cos(theta);
+            gs.sqy[s] = cy + 1.0 * r * sin(theta);
+            gs.sqth[s] = theta;
+          }
+          nreq |= mlist[ps] << (LP * ps);
+          if (ps + 1 < NP) {
+#pragma unroll
+            for (int q = 0; q < LP; ++q) theta += theta_res;
+          }
+        }
+        if (l == 0) gs.req[ia] = nreq;
       }
       if (any) {
         push_next = true;
@@ -1437,7 +1517,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       double theta = theta0;
       for (int q = 0; q < l; ++q) theta += theta_res;
       double ub[NP], umax = -1e300;
-      double sqx_l[NP], sqy_l[NP];
+      double sqx_l[NP], sqy_l[NP], th_l[NP];
       int kk[NP];
       bool valid[NP];
 #pragma unroll
@@ -1447,7 +1527,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         n_emit += __popc(ballot_g(valid[ps]));  // theta increases with j: the valid samples are a prefix
         ub[ps] = -1e300;
         kk[ps] = 0;
-        sqx_l[ps] = 0.0; sqy_l[ps] = 0.0;
+        sqx_l[ps] = 0.0; sqy_l[ps] = 0.0; th_l[ps] = 0.0;
         if (valid[ps]) {
           const size_t s = sample_slot(stride, ia, j);
           const double qx = cx + 1.0 * r * cos(theta);
@@ -1472,7 +1552,10 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             ub[ps] = u;
             gs.sq_ub[s] = u;
           }
+          th_l[ps] = theta;
+#if !SVSDF_LEAN_HANDOFF
           gs.sqx[s] = qx; gs.sqy[s] = qy; gs.sqth[s] = theta; gs.sq_sdf[s] = kUnsolved;
+#endif
         }
         if (ps + 1 < NP) {
 #pragma unroll
@@ -1514,7 +1597,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           if (valid[ps]) {
             const size_t s = sample_slot(stride, ia, l + LP * ps);
             gs.sq_ub[s] = ub[ps];
-            gs.sq_k[s] = kk[ps];
+            gs.sq_k[s] = kk[ps];   // (every emitted sample keeps its seed: a supplementary solve starts from it)
           }
       }
       if constexpr (MODE == 2) {
@@ -1618,13 +1701,19 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         umax = fmax(umax, Grp<LP>::template xchg<3>(umax));
         umax = fmax(umax, Grp<LP>::template xchg<4>(umax));
       }
+      unsigned nreq = 0u;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         list_me[ps] = valid[ps] && ub[ps] >= umax - delta;
         mlist[ps] = ballot_g(list_me[ps]);
+        nreq |= mlist[ps] << (LP * ps);
+        if (SVSDF_LEAN_HANDOFF && list_me[ps]) {   // the record of a requested sample: what its solve and the closing of the round read
+          const size_t s = sample_slot(stride, ia, l + LP * ps);
+          gs.sqx[s] = sqx_l[ps]; gs.sqy[s] = sqy_l[ps]; gs.sqth[s] = th_l[ps];
+        }
       }
       push_next = true;
-      if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = (int)kPhaseEval; }
+      if (l == 0) { gs.nsamp[ia] = n_emit; gs.phase[ia] = (int)kPhaseEval; gs.req[ia] = nreq; }
       SVSDF_PHASE(rc, 4, tph);
     }
   }
@@ -1763,7 +1852,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
       const int av = s_a[ent];
       if (av == -1) continue;
       const int a2 = av & 0x3fffffff;
-      const size_t ia2 = (size_t)start + a2;
+      const size_t ia2 = (size_t)a2;
       int pos = s_base[0] + s_off[0][ent];
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
@@ -1928,7 +2017,7 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
       if (ro.n_emit > 0) own = true;
       if (l == 0) n_emit_tot += ro.n_emit;
     }
-    const size_t ia = (size_t)start + (size_t)(a >= 0 ? a : 0);
+    const size_t ia = (size_t)(a >= 0 ? a : 0);
     if (ro.finished) a = -1;
     // ---- the wave's solve list: the selected samples of both halves
     const unsigned m_mine = (a >= 0) ? ro.mlist[0] : 0u;
@@ -1994,7 +2083,7 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
   }
 }
 
-#ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_api.hip
+#ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_pipeline.hip
 __global__ void __launch_bounds__(kBlock)
 k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
@@ -2142,6 +2231,7 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
     }
     stats_out[9 + kMaxIter] = rs;
     stats_out[10 + kMaxIter] = sp_;
+    stats_out[11 + 2 * kMaxIter] = (unsigned long long)ctl[0].n_int;   // interior points found (may exceed the capacity: repeat)
     for (int i = 0; i < kMaxIter; ++i) {   // active GSIP points per iteration: the host places the fused tail (k_tail) by them
       unsigned long long na = 0;
       for (int b = 0; b < nbatch; ++b) na += (unsigned long long)ctl[b].n_active[i];

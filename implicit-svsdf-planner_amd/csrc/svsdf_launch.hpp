@@ -2,7 +2,7 @@
 //
 // The kernels are specialised per shape id (17 shapes x lane-group widths x GSIP bound modes: ~250 kernels).  They are
 // compiled in SVSDF_NSLICES translation units (svsdf_shape_slice.hip with -DSVSDF_SLICE=k holds the shapes with
-// id % SVSDF_NSLICES == k) so that the build runs in parallel; svsdf_api.hip only sees these plain functions.
+// id % SVSDF_NSLICES == k) so that the build runs in parallel; svsdf_pipeline.hip only sees these plain functions.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,7 +29,7 @@ struct TailLaunch {    // arguments of k_tail<SHAPE, MODE>
 };
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
   const TrajDev *traj; ShapeParams sp; const double *px, *py, *sdf, *t; double *res_sdf, *res_t, *res_gx, *res_gy;
-  GsipState gs; BatchCtl *ctl;
+  GsipState gs; BatchCtl *ctl; int *n_int; int icap;
 };
 
 // each returns false when the shape id is not compiled into the library (development builds)

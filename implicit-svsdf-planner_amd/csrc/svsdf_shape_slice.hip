@@ -1,7 +1,7 @@
 // svsdf_shape_slice.hip -- one slice of the shape-templated kernels (compile with -DSVSDF_SLICE=k, k = 0 .. 3).
 //
 // Slice k instantiates k_solve / k_round / k_classify / k_rbound / k_subsw / k_shape_kernels for the shapes with
-// id % 4 == k and exports the launchers svsdf_api.hip dispatches to (svsdf_launch.hpp).  Splitting the ~250 kernel
+// id % 4 == k and exports the launchers svsdf_pipeline.hip dispatches to (svsdf_launch.hpp).  Splitting the ~250 kernel
 // instantiations over four translation units lets the build run in parallel (one TU took 140 s).
 #include <hip/hip_runtime.h>
 
@@ -96,7 +96,7 @@ bool classify_s(unsigned grid, size_t lds, hipStream_t st, const ClassifyLaunch 
     return false;
   } else {
     hipLaunchKernelGGL((k_classify<S>), dim3(grid), dim3(kBlock), lds, st, a.traj, a.sp, a.px, a.py, a.sdf, a.t,
-                       a.res_sdf, a.res_t, a.res_gx, a.res_gy, a.gs, a.ctl);
+                       a.res_sdf, a.res_t, a.res_gx, a.res_gy, a.gs, a.ctl, a.n_int, a.icap);
     return true;
   }
 }

@@ -199,3 +199,32 @@ def test_gsip_bound_modes_are_invisible(built):
             assert st1["solves"] < 0.6 * st0["solves"]
 
 
+
+
+def test_interior_capacity_grows_and_repeats(built, monkeypatch):
+    """The GSIP arrays are sized by the interior count, not by the cloud (round 4): an evaluation that finds more interior
+    points than the arrays hold drops the surplus, the library grows the arrays and repeats the evaluation.  Forced here
+    with a 64-entry start capacity: cost, gradients and every per-point result must equal the normal run bit for bit, also
+    after the trajectory moved (more interior points than the fitted capacity)."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make("C2", P=20000, minco=svsdf_amd.minco_coeffs)
+    kw = dict(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"], head_state=w["head_state"],
+              tail_state=w["tail_state"], device=0)
+    ref = svsdf_amd.SvsdfContext(**kw)
+    ref.set_points(w["points"])
+    monkeypatch.setenv("SVSDF_ICAP_INIT", "64")
+    small = svsdf_amd.SvsdfContext(**kw)
+    small.set_points(w["points"])
+    monkeypatch.delenv("SVSDF_ICAP_INIT")
+    wide = dict(kw, safety_hor=w["safety_hor"])
+    for k, scale in enumerate((1.0, 1.0, 0.97)):      # the third trajectory is another one: the interior set changes
+        q = w["q"] * scale
+        coeffs = svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], q, w["T"])
+        a = ref.eval_penalty(coeffs, w["T"])
+        b = small.eval_penalty(coeffs, w["T"])
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
+        qa, qb = ref.query_points(coeffs, w["T"]), small.query_points(coeffs, w["T"])
+        for x, y in zip(qa[:3], qb[:3]):
+            assert np.array_equal(x, y), k
+    assert small.stats()["interior_points"] == ref.stats()["interior_points"] > 64
