@@ -274,22 +274,30 @@ def combine_ab(r, a, devices, steps):
             out[f"{mode}_ms_per_step"] = None
             out["rccl_note"] = f"RCCL combine unavailable: {e}"
             continue
-        for _ in range(2):
-            r.step()
-        r.fence()
-        cm = 0.0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r.step()
-            cm += r.ctx.stats()["combine_ms"]
-        r.fence()
-        out[f"{mode}_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
-        out[f"{mode}_combine_only_ms"] = cm / steps
-        if mode == "rccl":
-            out["rccl_ranks"] = r.ctx.group_info()["rccl_ranks"]
+        try:
+            for _ in range(2):
+                r.step()
+            r.fence()
+            cm = 0.0
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r.step()
+                cm += r.ctx.stats()["combine_ms"]
+            r.fence()
+            out[f"{mode}_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+            out[f"{mode}_combine_only_ms"] = cm / steps
+            if mode == "rccl":
+                out["rccl_ranks"] = r.ctx.group_info()["rccl_ranks"]
+        except Exception as e:      # an all-reduce that fails must not take the headline measurement with it
+            out[f"{mode}_ms_per_step"] = None
+            out["rccl_note"] = f"{mode} combine failed: {e}"
+            break
     out["note"] = ("whole-evaluation time per step under each combine (same context, same stripes); *_combine_only_ms: host time "
                    "from 'all devices done' to 'summed partial on the host'; rccl_ranks: ncclCommCount of the communicator")
-    r.ctx.set_combine({"auto": "host", "host": "host", "rccl": "rccl"}[a.combine])
+    try:
+        r.ctx.set_combine({"auto": "host", "host": "host", "rccl": "rccl"}[a.combine])
+    except Exception:
+        pass
     return out
 
 

@@ -136,11 +136,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     }
     // candidate lists of the outline (svsdf_polygon.hpp), then one upload: the header's pointers are device addresses
     PolyAccelHost pa;
-    int ngf = 128, ngc = 256;   // grid cells per side, fine / coarse (env SVSDF_POLY_GRID="f,c": experiments)
-    if (const char *e = std::getenv("SVSDF_POLY_GRID")) {
-      int a = 0, b = 0;
-      if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 8 && a <= 1024 && b >= 8 && b <= 1024) { ngf = a; ngc = b; }
-    }
+    const int ngf = 128, ngc = 256;   // grid cells per side, fine / coarse
     if (!build_poly_accel(v.data(), (int)(v.size() / 2), pa, ngf, ngc)) return bail("svsdf_create: polygon outline rejected (non-finite vertex?)");
     auto align = [](size_t o) { return (o + 63) & ~(size_t)63; };
     const size_t o_edges = align(sizeof(PolyAccel));
@@ -173,29 +169,16 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
   if (const char *e = std::getenv("SVSDF_G_LATE")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_late = g; ctx->G_late_env = g; } }
   if (const char *e = std::getenv("SVSDF_PRUNE")) ctx->prune = std::atoi(e) != 0;
-  if (const char *e = std::getenv("SVSDF_BLOCK")) { const int b = std::atoi(e); ctx->block = (b == 128 || b == 256) ? b : 64; ctx->block_env = true; }
   if (const char *e = std::getenv("SVSDF_BATCHES")) ctx->want_batches = (std::string(e) == "measure") ? -1 : std::max(0, std::min(std::atoi(e), (int)kMaxBatches));
-  if (const char *e = std::getenv("SVSDF_WAVES_PER_CU")) ctx->waves_per_cu = std::max(1, std::min(std::atoi(e), 32));
-  if (const char *e = std::getenv("SVSDF_DELTA_ALL_ITER")) { ctx->delta_all_iter = std::atoi(e); ctx->all_iter_env = true; }
-  if (const char *e = std::getenv("SVSDF_ROUND_LP8_ITERS")) ctx->round_lp8_iters = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_SELECT_DELTA")) { ctx->select_delta = std::atof(e); ctx->select_env = true; }
   {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n > 0) ctx->n_cu = n;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && n > 0) ctx->lds_limit = (size_t)n;
   }
-  if (const char *e = std::getenv("SVSDF_FIRST_ITERS")) { ctx->first_iters = std::max(1, std::min(std::atoi(e), (int)kMaxIter)); ctx->adaptive_iters = false; }
-  if (const char *e = std::getenv("SVSDF_LATE_ITER")) ctx->late_iter = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_CULL")) ctx->cull = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL")) ctx->tail_mode = (std::string(e) == "off") ? -2 : (std::string(e) == "auto") ? -1 : std::max(0, std::atoi(e));
-  if (const char *e = std::getenv("SVSDF_TAIL_BELOW")) ctx->tail_below = std::atoll(e);
-  if (const char *e = std::getenv("SVSDF_TAIL_ALL_AFTER")) ctx->tail_all_after = std::atoi(e);
-  if (const char *e = std::getenv("SVSDF_ROUND_LIST")) ctx->round_list = std::atoi(e);
   if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_lazy = std::atoi(e) == 2; ctx->ub_env = true; }
-  if (const char *e = std::getenv("SVSDF_UB_RATIO")) { ctx->ub_threshold = std::atof(e); ctx->ub_thr_env = true; }
-  if (const char *e = std::getenv("SVSDF_WIDE32")) ctx->wide32_below = std::atoll(e);
-  if (const char *e = std::getenv("SVSDF_WIDE16")) ctx->wide16_below = std::atoll(e);
-  if (const char *e = std::getenv("SVSDF_WIDE8")) ctx->wide8_below = std::atoll(e);
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_PIECE_TIME")) {   // exact | fast | auto (default)
     ctx->cfg.flags &= ~(SVSDF_FLAG_EXACT_PIECE_TIME | SVSDF_FLAG_FAST_PIECE_TIME);

@@ -136,7 +136,8 @@ struct svsdf_ctx {
   bool have_prev_nsolve = false;
   // fused GSIP tail (k_tail): all iterations from tail_iter on in one launch per batch
   int tail_mode = -1;                    // -1: by the previous evaluation's active counts, -2: off (launch chain only), >= 0: pinned
-  long long tail_below = 16384;          // auto: the whole GSIP loop runs in k_tail when the shard has at most this many interior points
+  long long tail_below = 0;              // auto: the whole GSIP loop runs in k_tail when the shard has at most this many interior
+                                         // points; 0 = what one generation of waves holds (24 per CU: 6144 on 256 CUs)
   int tail_all_after = 1 << 30;          // steps of a point inside k_tail after which every sample is requested (-1: like the chain)
   int tail_iter = -1;                    // this evaluation: iteration the tail starts at (-1: none)
   long long prev_nactive[svsdf::kMaxIter] = {}; // active GSIP points per iteration of the previous evaluation, up to its tail

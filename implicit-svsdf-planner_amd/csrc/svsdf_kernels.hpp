@@ -1892,7 +1892,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
 // is finished:  close the round -> open the next -> select -> solve the selected samples IN THE WAVE -> close ... .  No
 // hand-off between workgroups, no list atomics, no block barrier after the table staging; a half-wave that has finished
 // its point takes the next one from the active list.  The solves of the wave's two points run together: the wave's
-// <= 48 selected samples are dealt out to lane groups of 8 (up to 8 queries) or 2 lanes, each group runs the very
+// <= 48 selected samples are dealt out to lane groups of 32 (up to 2 queries), 8 (up to 8) or 2 lanes, each group runs the very
 // scan_layer1 / descend_from_seed of k_solve (the descent's ladders share the wave as there).  Same per-sample and
 // per-point arithmetic as the launch chain, so identical bits whatever it0 is (the host picks it from the previous
 // evaluation's active counts).
@@ -1902,7 +1902,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
 // LDS: [Polygon edges | pose table 4K | chunks 4 nch | trajectory 20N+1] doubles, then kTailWaveLds bytes per wave.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTailBlock = 256;
-constexpr int kTailFetch = 8;     // points a wave takes from the active list per atomic
+constexpr int kTailFetch = 2;     // points a wave takes from the active list per atomic (8 made the last waves serialise four pairs each: + 1 ms beyond 6144 points)
 constexpr size_t kTailWaveLds = ((ladder_lds_bytes(2) + 15) & ~(size_t)15) + 2 * kMaxCand * sizeof(unsigned short) + 64 * sizeof(unsigned);
 template <int SHAPE, int G>
 __device__ __forceinline__ void tail_solve_pass(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
@@ -1946,14 +1946,14 @@ template <int SHAPE, int MODE>
 __global__ void __launch_bounds__(kTailBlock, SVSDF_TAIL_WAVES)
 k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
        const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_, const double *__restrict__ py_,
-       GsipState gs, size_t stride, int it0, int prev_mode, double delta, double band_delta, int all_after,
+       GsipState gs, size_t stride, int it0, int prev_mode, double delta, double band_delta, int all_after, int ppw,
        double *__restrict__ res_sdf, double *__restrict__ res_t, double *__restrict__ res_gx, double *__restrict__ res_gy,
        BatchCtl *__restrict__ ctl, int clist_on, int prune) {
   extern __shared__ double tail_lds[];
   constexpr int LP = 32;
   const int n_act = ctl->n_active[it0];
   const int wave_g = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (n_act <= 0 || (int)blockIdx.x * (kTailBlock / 64) * 2 >= n_act) return;   // block-uniform
+  if (n_act <= 0 || (int)blockIdx.x * (kTailBlock / 64) * ppw >= n_act) return;   // block-uniform
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
   stage_poly_edges<SHAPE>(sp, tail_lds);
@@ -1980,8 +1980,10 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   unsigned long long rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
   int n_emit_tot = 0;
   // work: the wave's first two points are its own (wave index: no atomic), further ones come kTailFetch at a time
-  const int n_static = (int)(gridDim.x * (blockDim.x >> 6)) * 2;
-  int q_next = wave_g * 2, q_end = min(wave_g * 2 + 2, n_act);   // wave-uniform
+  // ppw = points per wave: 2 (one per half-wave), or 1 when the launch holds few points -- a pure latency chain then, and
+  // a wave with one point's handful of samples solves them with wider lane groups
+  const int n_static = (int)(gridDim.x * (blockDim.x >> 6)) * ppw;
+  int q_next = wave_g * ppw, q_end = min(wave_g * ppw + ppw, n_act);   // wave-uniform
   bool exhausted = false;
   int a = -1;          // interior index of this half's point (-1: none)
   int steps = 0;       // GSIP steps this half's point has taken in this kernel
@@ -1991,7 +1993,7 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int ah = __builtin_amdgcn_readlane(a, hh * 32);
-      if (ah >= 0) continue;
+      if (ah >= 0 || hh >= ppw) continue;
       if (q_next >= q_end && !exhausted) {
         unsigned b = 0;
         if (lane == 0) b = atomicAdd(&ctl->work[min(it0 + 1, kWorkCounters - 1)], (unsigned)kTailFetch);
@@ -2034,7 +2036,9 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (nq > 0) {
-      if (nq <= 8) {
+      if (nq <= 2) {
+        tail_solve_pass<SHAPE, 32>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
+      } else if (nq <= 8) {
         tail_solve_pass<SHAPE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
       } else {
         for (int base = 0; base < nq; base += 32)

@@ -24,7 +24,7 @@ struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
 };
 struct TailLaunch {    // arguments of k_tail<SHAPE, MODE>
   const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py;
-  GsipState gs; size_t stride; int it0, prev_mode; double delta, band_delta; int all_after;
+  GsipState gs; size_t stride; int it0, prev_mode; double delta, band_delta; int all_after, ppw;
   double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl; int clist_on, prune;
 };
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>

@@ -205,11 +205,13 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
     if (ctx->launch_err.empty()) ctx->launch_err = "trajectory too long for the LDS pose table (k_tail)";
     return;
   }
-  const long long per_block = (kTailBlock / 64) * 2;
+  // one point per wave while that still fits the chip's wave slots (3 per SIMD): the launch is a latency chain then
+  const int ppw = (pts <= (long long)ctx->n_cu * 12) ? 1 : 2;
+  const long long per_block = (kTailBlock / 64) * ppw;
   const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((pts + per_block - 1) / per_block, (long long)ctx->n_cu * 3));
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const TailLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it0, mode,
-                     sel, ctx->select_delta, all_after, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
+                     sel, ctx->select_delta, all_after, ppw, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
                      ctx->d_ctl + b, ctx->round_list, ctx->prune};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
@@ -224,18 +226,20 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
 }
 
 // Iteration the fused tail starts at in this evaluation.  Measured (round 4, profiles/r04_tail_*): the launch chain packs the
-// solves of all points 32 to a wave and runs k_round at 4 waves per SIMD -- wherever a launch still holds more points than
-// the chip keeps in flight at two per wave it has several times the tail's throughput, and its last launches take 5 - 50 us
-// each, so at 100 k - 1 M points the tail only costs time (C2 + 6 %, C3 + 2 %, NS + 3 % with the threshold at 4096 points).
-// A small cloud is a pure latency chain of ~ 20 launches: there the whole GSIP loop runs in the tail (it0 = 0; C1, 10 k
-// points: 0.90 -> 0.76 ms).  Rule: every GSIP iteration in k_tail when the previous evaluation of this point set had at
-// most tail_below interior points, the launch chain otherwise; SVSDF_TAIL pins an iteration or turns the tail off.  Any
-// choice gives the same bits.
+// solves of all points 32 to a wave and runs k_round at 4 waves per SIMD -- once a launch holds more points than the chip
+// keeps in flight it has several times the tail's throughput, and its last launches take 5 - 50 us each, so placing the tail
+// late in the chain of a 100 k - 1 M cloud only costs time (C2 + 6 %, C3 + 2 %, NS + 3 % with a threshold of 4096 points).
+// A small cloud is a pure latency chain of ~ 20 launches: there the WHOLE GSIP loop runs in the tail (it0 = 0), as long as
+// its interior points fit one generation of waves (two per wave, 12 waves per CU: 6144 on this part).  C1 workload, chain
+// -> tail: 3 k points 0.68 -> 0.54 ms, 10 k (4.7 k interior) 0.89 -> 0.71, 13 k (6.1 k) 0.93 -> 0.75, 20 k (9.4 k) 1.09 ->
+// 1.06, 30 k (14 k) 1.24 -> 1.56 (tools/tail_scan.py).  SVSDF_TAIL / svsdf_set_plan pin an iteration or turn the tail
+// off.  Any choice gives the same bits.
 int choose_tail_iter(const svsdf_ctx *ctx) {
   if (ctx->tail_mode == -2) return -1;
   if (ctx->tail_mode >= 0) return std::min(ctx->tail_mode, (int)kMaxIter - 2);
   if (!ctx->have_prev_nactive) return -1;   // first evaluation of a point set: the interior count is not known yet
-  return (ctx->prev_nactive[0] <= ctx->tail_below) ? 0 : -1;
+  const long long below = ctx->tail_below > 0 ? ctx->tail_below : (long long)ctx->n_cu * 24;
+  return (ctx->prev_nactive[0] <= below) ? 0 : -1;
 }
 
 void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {

@@ -82,7 +82,7 @@ bool tail_s(int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunc
   } else {
 #define TAIL(MODE)                                                                                                   \
   hipLaunchKernelGGL((k_tail<S, MODE>), dim3(grid), dim3(kTailBlock), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp,  \
-                     a.px, a.py, a.gs, a.stride, a.it0, a.prev_mode, a.delta, a.band_delta, a.all_after, a.res_sdf,   \
+                     a.px, a.py, a.gs, a.stride, a.it0, a.prev_mode, a.delta, a.band_delta, a.all_after, a.ppw, a.res_sdf,   \
                      a.res_t, a.res_gx, a.res_gy, a.ctl, a.clist_on, a.prune)
     if (mode == 2) TAIL(2); else if (mode == 1) TAIL(1); else TAIL(0);
 #undef TAIL
