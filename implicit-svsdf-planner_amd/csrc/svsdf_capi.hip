@@ -475,7 +475,7 @@ int svsdf_set_plan(svsdf_ctx *ctx, const svsdf_plan *plan) {
   if (ctx->G_env) { ctx->G = g; if (!ctx->G_late_env) ctx->G_late = std::max(g, 8); }
   else if (ctx->points_set) {
     const size_t Ps = ctx->P;
-    ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : (ctx->cfg.shape_id == (int)kPolygon) ? 4 : 2;
+    ctx->G = default_lanes(ctx, Ps);
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
   }
   ctx->tail_mode = (plan->tail_iter == SVSDF_PLAN_AUTO) ? -1 : plan->tail_iter;

@@ -231,6 +231,15 @@ int dev_alloc(svsdf_ctx *ctx, T **p, size_t count) {
   return SVSDF_OK;
 }
 
+// Lanes per query of the main solve by shard size: small shards are latency chains (wide groups shorten them), large ones
+// throughput (narrow groups waste fewer lanes; the descent's ladders share the wave anyway).  Crossovers re-measured in
+// round 4 after the shared ladders (profiles/r04_lanes_sweep.txt: 100 k points 8 -> 4 lanes - 5 %, 200 k 8 -> 2 lanes - 7 %).
+// (Polygon: never below 4 -- its 2-lane kernel spills under the 3-waves register cap.)
+inline int default_lanes(const svsdf_ctx *ctx, size_t Ps) {
+  const int g = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 75000) ? 8 : (Ps < 150000) ? 4 : 2;
+  return (ctx->cfg.shape_id == (int)svsdf::kPolygon) ? std::max(g, 4) : g;
+}
+
 // ---- svsdf_pipeline.hip
 int set_batches(svsdf_ctx *ctx, int nb);
 int choose_tail_iter(const svsdf_ctx *ctx);

@@ -1003,7 +1003,7 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; }
   if (!ctx->G_env) {
     // (Polygon: 4 -- its 2-lane kernel spills 52 registers under the 3-waves cap; C5 36.5 vs 34.8 ms)
-    ctx->G = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 300000) ? 8 : (ctx->cfg.shape_id == (int)kPolygon) ? 4 : 2;
+    ctx->G = default_lanes(ctx, Ps);
     if (!ctx->G_late_env) ctx->G_late = std::max(ctx->G, 8);
   }
   return SVSDF_OK;
