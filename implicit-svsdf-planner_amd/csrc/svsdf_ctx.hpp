@@ -127,6 +127,8 @@ struct svsdf_ctx {
   int round_list = 3;          // k_round: per-point candidate-chunk lists (env SVSDF_ROUND_LIST: bit 0 scans, bit 1 cheap bound use them; 0: all chunks; same results)
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid
+  bool cull2 = true;           // second, value-based exact cull after the table scan (env SVSDF_CULL=1 turns only this one off)
+  double slack_max = 0.0;      // max over the chunks of the linear continuous-path allowance
   int G_env = 0, G_late_env = 0;
   // batch count of a large shard in the scanning bound modes: chosen by timing real evaluations (any split gives the
   // same bits): 0 idle / done, 1 next evaluation learns the launch plan with one batch, 2.. timing candidate bt_k

@@ -654,7 +654,8 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
                                             int nch, double px, double py, int prune, double cull_thresh,
                                             double &best_d, int &best_k, bool &culled, unsigned &n_scan,
                                             const unsigned short *clist = nullptr, int ncl = -1,
-                                            unsigned long long *sc = nullptr) {
+                                            unsigned long long *sc = nullptr, const double *__restrict__ rot = nullptr,
+                                            double slack_max = 0.0) {
   const int li = Grp<G>::li();
   best_d = 1e9;   // min_dis initial value (SWM:545)
   best_k = 0x7fffffff;
@@ -664,6 +665,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
   // (value, index) pairs meet once, at the end of the scan (finish_scan).  Same minimum, same earliest index.
   double d_lane = 1e300;
   int k_lane = 0x7fffffff;
+  double vbound = 1e300;   // min over the evaluated chunks of (table minimum of the chunk - allowance), main points only
   auto eval_chunk = [&](int c) {
     double d_loc = 1e300;
     constexpr int GS = (G < kChunk) ? G : kChunk;
@@ -685,6 +687,12 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
     if constexpr (G >= 16) d_loc = dmin(d_loc, Grp<G>::template xchg<3>(d_loc));
     if constexpr (G >= 32) d_loc = dmin(d_loc, Grp<G>::template xchg<4>(d_loc));
     if (d_loc < best_d) best_d = d_loc;
+    if constexpr (!LITE) {
+      if (rot) {   // second exact cull (round 4), see below: the chunk's table minimum less its continuous-path allowance
+        const Chunk ch = chunks[c];
+        vbound = dmin(vbound, d_loc - (ch.slack + rot[c] * (norm2(px - ch.cx, py - ch.cy) + ch.rb)));
+      }
+    }
   };
   auto finish_scan = [&]() {
     Grp<G>::min_dk(d_lane, k_lane);
@@ -770,6 +778,20 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
       c = c + first + 1;
     }
     if (!culled) finish_scan();
+    // Second exact cull (round 4; main points, shapes whose SDF is an exact distance function, i.e. 1-Lipschitz: all 17).
+    // The first one knows a chunk only by its bounding circle (|p - c| - rb: loose by up to the shape's circumradius --
+    // 15 % of C3's points are inactive yet survive it).  After the scan the table VALUES are known: for a time t of an
+    // EVALUATED chunk's interval, within h of a table time t_k,  q(t) = R(t)^T (p - x(t))  moves by at most
+    // h (V_c + W_c |p - x|)  (V_c, W_c: Bernstein bounds of planar speed and yaw rate on the interval, host), so
+    // sdf(t) >= sdf(t_k) - h (V_c + W_c (|p - c| + rb_c));  a PRUNED chunk has every table value above the running
+    // minimum and, by the circle argument,  sdf(t) >= lb_c - slack_c > best_d - max_c slack_c.  If the smaller of the two
+    // bounds exceeds safety_hor, every pose of the continuous path keeps the point inactive whatever local minimum the
+    // reference's search returns: it contributes exactly zero and the 215 evaluations of layers 2-4 and the descent
+    // are skipped.
+    if (!culled && rot) {
+      const double bound = dmin(vbound, best_d - slack_max) - 1e-9;
+      if (bound > cull_thresh) { culled = true; best_d = bound; best_k = 0; }
+    }
   }
 }
 
@@ -1086,7 +1108,8 @@ template <int SHAPE, int G, int U>
 __global__ void __launch_bounds__(kBlock, is_polygon<SHAPE>() ? 3 : SVSDF_SOLVE_WAVES)
 k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
-        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh) {
+        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh,
+        const double *__restrict__ rot, double slack_max) {
   extern __shared__ double solve_lds[];
   int n;
   const long long total = qs_total(qs, n);
@@ -1145,7 +1168,7 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
     }
     if (!qs.seed_k || best_k < 0) {   // no seed for this query (main points, cheap-bound samples, unscanned lazy samples)
       scan_layer1<SHAPE, G>(sp, pose, chunks, K, nch, px, py, prune, cull_thresh, best_d, best_k, culled, n_scan, nullptr, -1,
-                            sc);
+                            sc, rot, slack_max);
     }
     if (culled && li == 0) { out_sdf[slot] = best_d; out_t[slot] = 0.0; ++n_culled; }
     }  // live

@@ -16,6 +16,7 @@ constexpr int kNSlices = 4;
 struct SolveLaunch {   // arguments of k_solve<SHAPE, G, 1>
   const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; QuerySet qs;
   double *out_sdf, *out_t; int prune; BatchCtl *ctl; int work_idx; double cull_thresh;
+  const double *rot; double slack_max;   // second exact cull (main points): per-chunk yaw allowance W_c h, max_c of the linear one
 };
 struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
   const TrajDev *traj; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py; GsipState gs;

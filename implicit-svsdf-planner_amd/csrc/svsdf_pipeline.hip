@@ -129,7 +129,11 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
   const unsigned grid = (unsigned)std::min<long long>((lanes + blk - 1) / blk, (long long)(256 * ctx->waves_per_cu * 64) / blk);
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
-  const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh};
+  // (the second, value-based cull runs with the first one: main points of an evaluation that may cull)
+  const bool cull2 = std::isfinite(cull_thresh) && ctx->cull2;
+  const double *d_rot = d_tk + ctx->K + (ctx->K + kChunk - 1) / kChunk;
+  const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh,
+                      cull2 ? d_rot : nullptr, ctx->slack_max};
   if (!launch_k_solve(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds_total, st, a) && ctx->launch_err.empty())
     ctx->launch_err = "k_solve: shape not compiled into this build";
   if (ctx->profile) {
@@ -269,7 +273,7 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   size_t K = 0;
   for (double t = 0.0; t <= dur; t += 0.15) ++K;
   if (K < 1 || K > 16000) return fail(ctx, SVSDF_ERR_INVALID, "trajectory duration out of range for the scan table");
-  const size_t need = 19 * (size_t)N + K + (K + kChunk - 1) / kChunk;  // coeffs | T | tk | chunk slack
+  const size_t need = 19 * (size_t)N + K + 2 * ((K + kChunk - 1) / kChunk);  // coeffs | T | tk | chunk slack | chunk yaw allowance
   if (need > ctx->in_cap) {
     const size_t cap = need + 4096;
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
@@ -305,23 +309,26 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
     // and smoothedL1 (BEO:316-340) is inactive.  Only in the regular regime (traj_duration not stale).
     const size_t nch = (K + kChunk - 1) / kChunk;
     double *slack = ctx->h_in + 19 * (size_t)N + K;
+    double *rot = slack + nch;   // W_c * h: yaw-rate allowance of the value-based second cull (scan_layer1)
+    ctx->slack_max = 0.0;
     const double *tk = ctx->h_in + 19 * (size_t)N;
     ctx->cull_ok = (td == dur) && K >= 1;
     std::vector<double> S(N + 1, 0.0);
     for (int i = 0; i < N; ++i) S[i + 1] = S[i] + T[i];
     for (size_t c = 0; c < nch; ++c) {
       slack[c] = std::numeric_limits<double>::infinity();
+      rot[c] = std::numeric_limits<double>::infinity();
       if (!ctx->cull_ok) continue;
       const size_t k0 = c * kChunk, k1 = std::min(k0 + kChunk, K) - 1;
       const double h = (c + 1 == nch) ? std::max(0.0751, dur - tk[k1]) : 0.0751;
       const double ta = std::max(0.0, tk[k0] - h), tb = std::min(td, tk[k1] + h);
-      double v2 = 0.0;
+      double v2 = 0.0, wmax = 0.0;
       for (int i = 0; i < N; ++i) {
         const double a = std::max(ta, S[i]) - S[i], b = std::min(tb, S[i + 1]) - S[i];  // local times in piece i
         if (!(b >= a)) continue;
         const double w = b - a;
-        double bound[2] = {0.0, 0.0};
-        for (int d = 0; d < 2; ++d) {
+        double bound[3] = {0.0, 0.0, 0.0};
+        for (int d = 0; d < 3; ++d) {
           double p[5];  // velocity in s: p[k] = (k+1) c_{k+1}
           for (int k = 0; k < 5; ++k) p[k] = (k + 1) * coeffs[(size_t)d * 6 * N + 6 * i + k + 1];
           for (int j = 0; j < 4; ++j)          // Taylor shift s = a + s' (repeated synthetic division)
@@ -336,9 +343,12 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
           }
         }
         v2 = std::max(v2, std::hypot(bound[0], bound[1]));
+        wmax = std::max(wmax, bound[2]);
       }
       const double sl = v2 * (1.0 + 1e-9) * h + 1e-9;
-      if (std::isfinite(sl)) slack[c] = sl;
+      if (std::isfinite(sl)) { slack[c] = sl; ctx->slack_max = std::max(ctx->slack_max, sl); }
+      const double rl = wmax * (1.0 + 1e-9) * h + 1e-12;
+      if (std::isfinite(rl)) rot[c] = rl;
     }
   }
   {

@@ -40,7 +40,7 @@ bool solve_s(int G, unsigned grid, unsigned block, size_t lds, hipStream_t st, c
   } else {
 #define SOLVE(GG)                                                                                                   \
   hipLaunchKernelGGL((k_solve<S, GG, 1>), dim3(grid), dim3(block), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp,    \
-                     a.qs, a.out_sdf, a.out_t, a.prune, a.ctl, a.work_idx, a.cull_thresh)
+                     a.qs, a.out_sdf, a.out_t, a.prune, a.ctl, a.work_idx, a.cull_thresh, a.rot, a.slack_max)
     // G lanes per query (G candidates / samples per step); the U = 2 interleaving (two evaluations per lane) was
     // measured and dropped, only U = 1 is instantiated
     switch (G) {

@@ -130,8 +130,8 @@ def test_inlined_sincos_is_bit_identical_to_device_library(built):
 
 
 def test_exact_cull_is_invisible(built):
-    """The exact cull (points proven inactive from the chunk bounds plus a rigorous continuous-path allowance skip
-    the argmin solve) must not change cost or gradient, and may only ever drop points whose true
+    """The exact cull (points proven inactive from the chunk bounds -- and, second stage, from the scanned table values --
+    plus a rigorous continuous-path allowance skip the argmin solve) must not change cost or gradient, and may only ever drop points whose true
     SVSDF exceeds safety_hor (checked against the un-culled per-point query)."""
     import svsdf_amd
     from svsdf_amd import workload
@@ -146,14 +146,17 @@ def test_exact_cull_is_invisible(built):
             sdf = ctx.query_points(w["coeffs"], w["T"])[0]   # query_points never culls
             return out, st, sdf
         (c0, gT0, gC0), st0, sdf0 = _with_env(dict(SVSDF_CULL=0), run)
-        (c1, gT1, gC1), st1, sdf1 = _with_env(dict(SVSDF_CULL=1), run)
         inactive = int((sdf0 > w["safety_hor"]).sum())
-        assert st0["culled_points"] == 0 and 0 < st1["culled_points"] <= inactive
-        assert st1["solves"] == st0["solves"] - st1["culled_points"]
-        np.testing.assert_array_equal(sdf0, sdf1)
-        assert c1 == c0                                          # same non-zero terms, deterministic assembly
-        np.testing.assert_array_equal(gT1, gT0)
-        np.testing.assert_array_equal(gC1, gC0)
+        prev = 0
+        for level in (1, 2):    # 1: the chunks' bounding circles; 2 (default): also the scanned table values (round 4)
+            (c1, gT1, gC1), st1, sdf1 = _with_env(dict(SVSDF_CULL=level), run)
+            assert st0["culled_points"] == 0 and prev < st1["culled_points"] <= inactive
+            assert st1["solves"] == st0["solves"] - st1["culled_points"]
+            np.testing.assert_array_equal(sdf0, sdf1)
+            assert c1 == c0                                          # same non-zero terms, deterministic assembly
+            np.testing.assert_array_equal(gT1, gT0)
+            np.testing.assert_array_equal(gC1, gC0)
+            prev = st1["culled_points"]
     # stale-duration regime (total >= 300 s after a shorter trajectory): the cull switches itself off
     w = workload.make("C2", P=20000, minco=svsdf_amd.minco_coeffs)
     ctx = _ctx(w)
