@@ -112,7 +112,14 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   sp.tx = cfg->poly_params[0];
   sp.ty = cfg->poly_params[1];
   const double yaw = cfg->poly_params[2] * kPI / 180.0;
-  sp.r00 = std::cos(yaw); sp.r01 = -std::sin(yaw); sp.r10 = std::sin(yaw); sp.r11 = std::cos(yaw);
+  // Rotate (SHP:287-292) is written with std::cos(yaw) / std::sin(yaw); g++ -O3 -- the reference's build -- merges such a
+  // pair into ONE call of sincos(), and glibc's sincos is not bit-identical with its cos / sin (yaw = -72.42 deg: cos one
+  // ulp apart).  So: sincos, explicitly (the oracle does the same; found by the device-arithmetic fuzz, round 4).
+  {
+    double sn_ = 0.0, cs_ = 1.0;
+    ::sincos(yaw, &sn_, &cs_);
+    sp.r00 = cs_; sp.r01 = -sn_; sp.r10 = sn_; sp.r11 = cs_;
+  }
   switch (cfg->shape_id) {
     case SVSDF_SHAPE_sdHorseshoe: sp.c0x = std::cos(20.5); sp.c0y = std::sin(20.5); break;
     case SVSDF_SHAPE_sdPie: sp.c0x = std::cos(43.0); sp.c0y = std::sin(43.0); break;
@@ -397,6 +404,16 @@ int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[20]) {
   return SVSDF_OK;
 }
 #endif
+
+int svsdf_debug_sdf_at(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, size_t n, const double *points_xy,
+                       const double *t, double *out8) {
+  if (!ctx || !coeffs || !T || (n && (!points_xy || !t || !out8))) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_debug_sdf_at: null argument");
+  if (ctx->host_only) return fail(ctx, SVSDF_ERR_NO_DEVICE, "host-only context: no device entry points");
+  if (!ctx->subs.empty()) return svsdf_debug_sdf_at(ctx->subs[0], N, coeffs, T, n, points_xy, t, out8);
+  if (n == 0) return SVSDF_OK;
+  if (n > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_debug_sdf_at: too many queries");
+  return debug_sdf_at(ctx, N, coeffs, T, n, points_xy, t, out8);
+}
 
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
   if (!ctx) return SVSDF_ERR_INVALID;

@@ -265,6 +265,7 @@ int plan_cloud(svsdf_ctx *ctx, const double *d_xyz, size_t P, CloudPlan &plan);
 int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int rk, int ws);
 int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, int ws);
 long long sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, int n);
+int debug_sdf_at(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, size_t n, const double *pxy, const double *t, double *out8);
 int site_stats(svsdf_ctx *ctx, unsigned long long out[20]);
 // ---- svsdf_group.hip
 int upload_group_device(svsdf_ctx *ctx, const double *d_xyz, size_t P);

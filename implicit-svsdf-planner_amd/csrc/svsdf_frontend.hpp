@@ -82,4 +82,27 @@ k_shape_kernels(ShapeParams sp, int ks, int count, double resu, int size_side, d
   }
 }
 
+// Diagnostic / test kernel (svsdf_debug_sdf_at): getSDFAtTimeStamp<false> (SWM:741-750) for arbitrary (point, time) pairs
+// through the very pose_at / sdf_from_pose the solve kernels inline, with the intermediates: out[8 i ..] = sdf, x, y, cos,
+// sin, body-frame x, body-frame y, piece-local-time path taken (0 cumulative, 1 / 2 chain).  One wave per block: the
+// faithful piece-time chain works on whole waves.
+template <int SHAPE>
+__global__ void __launch_bounds__(64)
+k_debug_sdf_at(const TrajDev *__restrict__ trg, ShapeParams sp, const double *__restrict__ pxy, const double *__restrict__ t_,
+               int n, double *__restrict__ out) {
+  extern __shared__ double dbg_lds[];
+  const TrajL tr = stage_traj(trg, dbg_lds);
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  PieceCache pc = piece_cache_init();
+  const Pose p = pose_at(tr, t_[i], pc);
+  const double px = pxy[2 * i], py = pxy[2 * i + 1];
+  const double dx = px - p.x, dy = py - p.y;
+  const double rx = p.cs * dx + p.sn * dy;
+  const double ry = (-p.sn) * dx + p.cs * dy;
+  double *o = out + 8 * (size_t)i;
+  o[0] = sdf_from_pose<SHAPE>(sp, p, px, py);
+  o[1] = p.x; o[2] = p.y; o[3] = p.cs; o[4] = p.sn; o[5] = rx; o[6] = ry; o[7] = (double)tr.exact;
+}
+
 }  // namespace svsdf

@@ -43,6 +43,8 @@ bool launch_k_subsw(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const 
                     const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);
 bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu,
                             int size_side, double safemargin, const double *yaw, unsigned char *map);
+bool launch_k_debug_sdf_at(int shape, unsigned grid, size_t lds, hipStream_t st, const TrajDev *traj, ShapeParams sp,
+                           const double *pxy, const double *t, int n, double *out);
 
 // per-slice entry points (defined by svsdf_shape_slice.hip, one set per slice)
 #define SVSDF_DECLARE_SLICE(K)                                                                                              \
@@ -54,7 +56,9 @@ bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParam
   bool launch_k_subsw_s##K(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,    \
                            const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag);         \
   bool launch_k_shape_kernels_s##K(int shape, unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu,   \
-                                   int size_side, double safemargin, const double *yaw, unsigned char *map);
+                                   int size_side, double safemargin, const double *yaw, unsigned char *map);                   \
+  bool launch_k_debug_sdf_at_s##K(int shape, unsigned grid, size_t lds, hipStream_t st, const TrajDev *traj, ShapeParams sp,    \
+                                  const double *pxy, const double *t, int n, double *out);
 SVSDF_DECLARE_SLICE(0)
 SVSDF_DECLARE_SLICE(1)
 SVSDF_DECLARE_SLICE(2)

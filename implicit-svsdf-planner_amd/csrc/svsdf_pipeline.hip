@@ -86,6 +86,11 @@ bool launch_k_subsw(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const 
   shape = svsdf_impl::compiled_shape(shape);
   SVSDF_SLICE_DISPATCH(launch_k_subsw, grid, st, sp, father, child, offs, pts, kt, nkt, flag)
 }
+bool launch_k_debug_sdf_at(int shape, unsigned grid, size_t lds, hipStream_t st, const TrajDev *traj, ShapeParams sp,
+                           const double *pxy, const double *t, int n, double *out) {
+  shape = svsdf_impl::compiled_shape(shape);
+  SVSDF_SLICE_DISPATCH(launch_k_debug_sdf_at, grid, lds, st, traj, sp, pxy, t, n, out)
+}
 bool launch_k_shape_kernels(int shape, unsigned grid, hipStream_t st, ShapeParams sp, int ks, int count, double resu,
                             int size_side, double safemargin, const double *yaw, unsigned char *map) {
   shape = svsdf_impl::compiled_shape(shape);
@@ -1027,6 +1032,36 @@ int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, i
   rc = take_stripe(ctx, ctx, plan, rk, ws);
   plan.release();
   return rc;
+}
+
+// svsdf_debug_sdf_at: upload the trajectory (same path as an evaluation: k_prep, piece-time mode), evaluate on the device
+int debug_sdf_at(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, size_t n, const double *pxy, const double *t,
+                 double *out8) {
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->ev_used = 0;
+  const size_t e0 = next_event(ctx);
+  (void)hipEventRecord(ctx->ev_pool[e0], ctx->stream);
+  int rc = upload_traj(ctx, N, coeffs, T);
+  if (rc) return rc;
+  double *d_p = nullptr, *d_t = nullptr, *d_o = nullptr;
+  auto cleanup = [&]() { for (void *q : {(void *)d_p, (void *)d_t, (void *)d_o}) if (q) (void)hipFree(q); };
+  hipError_t e = hipMalloc((void **)&d_p, 2 * n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_t, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_o, 8 * n * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_p, pxy, 2 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    const size_t lds = (size_t)traj_lds_doubles(N) * sizeof(double);
+    if (!launch_k_debug_sdf_at(ctx->cfg.shape_id, (unsigned)((n + 63) / 64), lds, ctx->stream, ctx->d_traj, ctx->sp, d_p, d_t, (int)n, d_o)) {
+      cleanup();
+      return fail(ctx, SVSDF_ERR_INVALID, "svsdf_debug_sdf_at: shape not compiled into this build");
+    }
+    e = hipMemcpyAsync(out8, d_o, 8 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) return fail(ctx, SVSDF_ERR_HIP_BASE + (int)e, std::string("svsdf_debug_sdf_at: ") + hipGetErrorString(e));
+  return SVSDF_OK;
 }
 
 // mismatch count of the kernels' inlined sincos against the device library's (svsdf_debug_sincos_mismatches)

@@ -133,6 +133,17 @@ bool shape_kernels_s(unsigned grid, hipStream_t st, ShapeParams sp, int ks, int 
   }
 }
 
+template <int S>
+bool debug_sdf_at_s(unsigned grid, size_t lds, hipStream_t st, const TrajDev *traj, ShapeParams sp, const double *pxy,
+                    const double *t, int n, double *out) {
+  if constexpr (!shape_enabled<S>()) {
+    return false;
+  } else {
+    hipLaunchKernelGGL((k_debug_sdf_at<S>), dim3(grid), dim3(64), lds, st, traj, sp, pxy, t, n, out);
+    return true;
+  }
+}
+
 }  // namespace
 
 #define SLICE_SWITCH(CALL)                                        \
@@ -173,6 +184,12 @@ bool SLICE_FN(launch_k_rbound)(int shape, unsigned grid, hipStream_t st, ShapePa
 bool SLICE_FN(launch_k_subsw)(int shape, dim3 grid, hipStream_t st, ShapeParams sp, const double *father, const double *child,
                               const unsigned long long *offs, const double *pts, const double *kt, int nkt, int *flag) {
 #define CALL(S) subsw_s<S>(grid, st, sp, father, child, offs, pts, kt, nkt, flag)
+  SLICE_SWITCH(CALL)
+#undef CALL
+}
+bool SLICE_FN(launch_k_debug_sdf_at)(int shape, unsigned grid, size_t lds, hipStream_t st, const TrajDev *traj, ShapeParams sp,
+                                     const double *pxy, const double *t, int n, double *out) {
+#define CALL(S) debug_sdf_at_s<S>(grid, lds, st, traj, sp, pxy, t, n, out)
   SLICE_SWITCH(CALL)
 #undef CALL
 }

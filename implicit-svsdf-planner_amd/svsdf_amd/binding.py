@@ -29,7 +29,7 @@ EXPORTS = [
     "svsdf_lbfgs_params_default", "svsdf_lbfgs_minimize", "svsdf_optimize_traj",
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
     "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline", "svsdf_outline_extrude",
-    "svsdf_get_plan", "svsdf_set_plan", "svsdf_set_combine", "svsdf_group_info",
+    "svsdf_get_plan", "svsdf_set_plan", "svsdf_set_combine", "svsdf_group_info", "svsdf_debug_sdf_at",
 ]
 
 
@@ -168,10 +168,11 @@ def lib():
     L.svsdf_swept_outline.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, C.c_size_t,
                                       C.POINTER(C.c_size_t), _ip, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.POINTER(OutlineStats)]
-    L.svsdf_get_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
-    L.svsdf_set_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
-    L.svsdf_set_combine.argtypes = [C.c_void_p, C.c_int]
-    L.svsdf_group_info.argtypes = [C.c_void_p, _ip, _ip, _ip]
+    if hasattr(L, "svsdf_get_plan"):   # (absent only from A/B libraries built from older commits, tools/exp_variants.py)
+        L.svsdf_get_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
+        L.svsdf_set_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
+        L.svsdf_set_combine.argtypes = [C.c_void_p, C.c_int]
+        L.svsdf_group_info.argtypes = [C.c_void_p, _ip, _ip, _ip]
     _LIB = L
     return L
 
@@ -600,6 +601,18 @@ class SvsdfContext:
                                              m.ctypes.data_as(u8), b.ctypes.data_as(u8), _p(yaws), C.byref(n)),
                   "svsdf_shape_kernels")
         return m.astype(bool), b, yaws, n.value
+
+    def debug_sdf_at(self, coeffs, T, points_xy, t):
+        """SDF-at-time of (point, time) pairs on the device with its intermediates (svsdf_debug_sdf_at): (n, 8) array
+        sdf, pose x, y, cos, sin, body-frame x, y, piece-time mode."""
+        T = _f64(T)
+        cm = _colmajor(coeffs)
+        xy = _f64(points_xy).reshape(-1, 2).copy()
+        tt = _f64(t).ravel().copy()
+        out = np.zeros((len(tt), 8))
+        self.L.svsdf_debug_sdf_at.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp, _dp]
+        self._chk(self.L.svsdf_debug_sdf_at(self.ctx, len(T), _p(cm), _p(T), len(tt), _p(xy), _p(tt), _p(out)), "svsdf_debug_sdf_at")
+        return out
 
     def sincos_mismatches(self, lo, hi, n):
         return int(self.L.svsdf_debug_sincos_mismatches(self.ctx, float(lo), float(hi), int(n)))

@@ -424,6 +424,12 @@ int svsdf_set_profiling(svsdf_ctx *ctx, int enable);
 /* Self-check: number of n equispaced arguments in [lo, hi] for which the kernels' inlined sincos
  * differs by even one bit from the ROCm device library's sincos (must be 0); -1 on error. */
 long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, int n);
+/* Diagnostic / test: getSDFAtTimeStamp<false> (sw_manager.hpp:741-750) of n (point, time) pairs on the device, through
+ * the code the solve kernels inline.  points_xy: n x 2, t: n; out8: n x 8 = sdf, pose x, y, cos(yaw), sin(yaw), body-frame
+ * x, y of the point, piece-time mode (0 cumulative, 1 / 2 the reference's chain).  The unit of work of the whole path:
+ * tests compare it bit for bit with the oracle in device-arithmetic mode for every shape. */
+int svsdf_debug_sdf_at(svsdf_ctx *ctx, int N, const double *coeffs_colmajor, const double *T, size_t n,
+                       const double *points_xy, const double *t, double *out8);
 /* Original indices (into the array given to svsdf_set_points) of this rank's shard, in the
  * order svsdf_query_points reports them. */
 int svsdf_shard_indices(const svsdf_ctx *ctx, long long *idx_out);

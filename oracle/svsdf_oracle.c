@@ -6,6 +6,7 @@
  * reference is built -O3 without -march / -ffast-math (src/planner_algorithm/
  * CMakeLists.txt:4), so x86-64 GCC emits no FMA; -ffp-contract=off keeps that here.
  */
+#define _GNU_SOURCE   /* sincos() */
 #include "svsdf_oracle.h"
 
 #include <math.h>
@@ -69,10 +70,14 @@ void orc_shape_init(orc_shape *s, int id, const double poly_params[3], const dou
   s->tx = poly_params ? poly_params[0] : 0.0;
   s->ty = poly_params ? poly_params[1] : 0.0;
   double yaw = (poly_params ? poly_params[2] : 0.0) * ORC_PI / 180.0;
-  s->r00 = cos(yaw);
-  s->r01 = -sin(yaw);
-  s->r10 = sin(yaw);
-  s->r11 = cos(yaw);
+  /* std::cos(yaw) / std::sin(yaw) in the reference (SHP:289-292); its g++ -O3 build merges the pair into one sincos()
+   * call (cse_sincos), whose results differ from cos() / sin() in the last bit for some arguments: explicit here, so
+   * that this file does not depend on what the compiler merges */
+  {
+    double sn_, cs_;
+    sincos(yaw, &sn_, &cs_);
+    s->r00 = cs_; s->r01 = -sn_; s->r10 = sn_; s->r11 = cs_;
+  }
   s->hs_cx = cos(20.5);  s->hs_cy = sin(20.5);      /* SHP:855 (radians) */
   s->pie_cx = cos(43.0); s->pie_cy = sin(43.0);     /* SHP:1237 */
   s->pie2_cx = cos(1.0); s->pie2_cy = sin(1.0);     /* SHP:1278 */
@@ -585,7 +590,7 @@ static inline unsigned long long dbits(double a) { unsigned long long u; memcpy(
 static inline void trig_sincos(const orc_ctx *ctx, double a, double *sn, double *cs) {
   if (ctx->trig_mode == 1) dev_sincos(a, sn, cs);
   else {
-    *sn = sin(a); *cs = cos(a);
+    sincos(a, sn, cs);   /* Eigen's AngleAxis computes sin(angle), cos(angle): one sincos() call in a g++ -O3 build */
     if (ctx->trig_mode == 2) {
       *sn = ulp_nudge(*sn, dbits(a) ^ ctx->trig_seed);
       *cs = ulp_nudge(*cs, dbits(a) ^ (ctx->trig_seed * 0x9e3779b97f4a7c15ULL + 1ULL));

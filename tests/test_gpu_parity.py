@@ -299,89 +299,15 @@ def test_bit_identical_when_oracle_uses_device_trig(built, config, P):
 def test_differential_fuzz_bit_identical_in_device_arithmetic_mode(built):
     """Same kind of random cases as test_differential_fuzz (all 17 shapes incl. mesh outlines, shape offsets, 1-6 unequal
     pieces, degenerate points), with the oracle in device-arithmetic mode: not one of the per-point (t*, SVSDF) values
-    may differ in any bit, and cost / gradients agree to summation order (1e-12).  Two seeds, one of them nobody chose."""
-    for seed in (11, _source_seed() + 1):
+    may differ in any bit, and cost / gradients agree to summation order (1e-12).  Fixed seeds: 11 and 457738 -- the
+    latter is the commit-derived seed that, in round 4, found the shape rotation one ulp off (cos / sin vs glibc's sincos,
+    tests/test_gpu_sdf_at.py); a seed derived from the current commit is added with SVSDF_FUZZ_NIGHTLY=1 (it changes
+    with every commit, so it is not part of the blocking set; it is printed)."""
+    seeds = [11, 457738]
+    if os.environ.get("SVSDF_FUZZ_NIGHTLY") == "1":
+        seeds.append(_source_seed() + 1)
+    for seed in seeds:
         worst, out = _fuzz(40, seed, FUZZ_DEGENERATE="1", FUZZ_DEVICE_TRIG="1")
+        print(f"seed {seed}: {worst}")
         assert worst["not_identical"] == 0, out[-3000:]
         assert worst["cost"] <= 1e-12 and worst["gC"] <= 1e-12 and worst["gT"] <= 1e-12 and worst["flips"] == 0.0, out[-2000:]
-
-
-def test_limits(built):
-    """Limits of the boundary: 64 pieces (kMaxPieces) work and agree with the oracle, 65 are refused; durations just
-    below and above the 300 s traj_duration gate (SWM:380-384); non-finite inputs are refused, never propagated."""
-    import svsdf_amd
-    from svsdf_amd import workload
-    w, ctx, o = _mk("C2", 3000, N=64)
-    assert len(w["T"]) == 64
-    cost, gT, gC = ctx.eval_penalty(w["coeffs"], w["T"])
-    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
-    assert abs(cost - ocost) <= 1e-7 * abs(ocost) and _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5
-    T65 = np.full(65, 1.0)
-    with pytest.raises(svsdf_amd.SvsdfError):
-        ctx.eval_penalty(np.zeros((6 * 65, 3)), T65)
-    # 290 s (regular regime, K = 1934 table poses) and 310 s after it (gate: the scan keeps the 290 s duration)
-    w2, ctx2, o2 = _mk("C2", 1500)
-    for scale in (7.25, 7.75):
-        T = np.asarray(w2["T"]) * scale
-        c = svsdf_amd.minco_coeffs(w2["head_state"], w2["tail_state"], w2["q"], T)
-        cost, gT, gC = ctx2.eval_penalty(c, T)
-        o2.set_traj(c, T)
-        ocost, ogT, ogC = o2.penalty(w2["points"], nthreads=NT, sum_mode=1)
-        assert abs(o2.duration() - 290.0) < 1e-9
-        assert abs(cost - ocost) <= 1e-7 * abs(ocost) and _rel(gC, ogC) <= 1e-5, (scale, cost, ocost)
-    # non-finite inputs
-    bad = w2["coeffs"].copy(); bad[3, 1] = np.nan
-    with pytest.raises(svsdf_amd.SvsdfError):
-        ctx2.eval_penalty(bad, w2["T"])
-    with pytest.raises(svsdf_amd.SvsdfError):
-        ctx2.set_points(np.array([[1.0, np.inf, 0.0]]))
-    with pytest.raises(svsdf_amd.SvsdfError):
-        ctx2.lmbm_evaluate(np.full(4 * 16 - 3, np.nan))
-    # the raw C callback (what LMBM would call) has no error channel: +inf and a zero gradient, never NaN
-    import ctypes as C
-    x = np.full(4 * 16 - 3, np.nan)
-    g = np.ones_like(x)
-    dp = C.POINTER(C.c_double)
-    f = svsdf_amd.lib().svsdf_lmbm_evaluate(ctx2.ctx, x.ctypes.data_as(dp), g.ctypes.data_as(dp), len(x))
-    assert np.isinf(f) and f > 0 and not g.any()
-
-
-def test_exact_piece_time_mode(built):
-    """Piece-local time by the reference's successive subtractions (TRJ:498-516): what the library does by default for
-    generic durations (SVSDF_FLAG_EXACT_PIECE_TIME forces it, SVSDF_FLAG_FAST_PIECE_TIME forces the single subtraction).
-    With it the only arithmetic the HIP path does not share with the reference is libm's sin/cos/atan2: against the
-    oracle run with device-library trig and the reference's own piece location (set_modes(1, 0)) every per-point value
-    is bit-identical on trajectories with UNEQUAL piece durations; the fast form matches the oracle's cumulative mode."""
-    import svsdf_amd
-    from svsdf_amd import workload
-    rng = np.random.default_rng(21)
-    w = workload.make(dict(shape="sdHorseshoe", N=7, P=2500, scenario="sdHorseshoe"), minco=svsdf_amd.minco_coeffs)
-    T = rng.uniform(0.7, 3.3, 7)                                  # unequal durations: the partial sums round
-    coeffs = svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], w["q"], T)
-    kw = dict(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
-              head_state=w["head_state"], tail_state=w["tail_state"], device=0)
-    o = orc.Oracle(w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
-                   head_state=w["head_state"], tail_state=w["tail_state"])
-    o.set_traj(coeffs, T)
-    res = {}
-    for name, flags, cum in (("exact", svsdf_amd.FLAG_EXACT_PIECE_TIME, 0), ("auto", 0, 0),
-                             ("default", svsdf_amd.FLAG_FAST_PIECE_TIME, 1)):
-        ctx = svsdf_amd.SvsdfContext(flags=flags, **kw)
-        ctx.set_points(w["points"])
-        sdf, ts, g, _ = ctx.query_points(coeffs, T)
-        cost, gT, gC = ctx.eval_penalty(coeffs, T)
-        o.set_modes(1, cum)                                       # device trig + the matching piece location
-        osdf, ots, og = o.query(w["points"], nthreads=NT)
-        assert np.array_equal(sdf, osdf) and np.array_equal(ts, ots), name
-        assert np.array_equal(g, og), name
-        assert ctx.stats()["piece_time_exact"] == (0 if name == "default" else 1)   # generic durations: auto = chain
-        res[name] = (cost, gC, ts)
-        ctx.close()
-    assert res["auto"][0] == res["exact"][0] and np.array_equal(res["auto"][1], res["exact"][1])
-    # the two forms are different arithmetic (they need not agree to the bit) but the same result to ~1e-9
-    assert abs(res["exact"][0] - res["default"][0]) <= 1e-9 * abs(res["default"][0])
-    assert _rel(res["exact"][1], res["default"][1]) <= 1e-6
-    # against the oracle of record (glibc trig, reference piece location) the exact mode stays inside the gates
-    o.set_modes(0, 0)
-    ocost, ogT, ogC = o.penalty(w["points"], nthreads=NT, sum_mode=1)
-    assert abs(res["exact"][0] - ocost) <= 1e-7 * abs(ocost) and _rel(res["exact"][1], ogC) <= 1e-5
