@@ -160,7 +160,7 @@ class Runner:
         st = self.ctx.stats()
         return {"set_points_ms": self.set_points_ms, "set_points_library_ms": st["setup_ms"],
                 "first_evaluation_ms": first_ms, "settle_evaluations": n, "batches": st["batches"],
-                "gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][st["gsip_bound_mode"]],
+                "gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan", "anchor-scan"][st["gsip_bound_mode"]],
                 "bound_ratio": st["bound_ratio"], "rule": "deterministic, from the first evaluation's counters: GSIP solves / "
                 "samples > 0.5 (Polygon 0.2) -> full-scan; else lazy-scan from 400 k points per device, cheap-chunk below; "
                 "batches: 1 / 3 / 4 timed once each on a large shard in a scanning mode, fastest kept"}
@@ -404,7 +404,7 @@ def quick_run(name, P, steps, local_rank, generic=False):
            "ms_per_step": ms, "ms_per_step_median": float(np.median(per)), "value": P / (ms * 1e-3), "unit": "query-points/s",
            "set_points_ms": set_ms,
            "settle_evaluations": n_settle, "interior_fraction": st["interior_points"] / max(st["points"], 1),
-           "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][pl["bound_mode"]], "batches": pl["batches"],
+           "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan", "anchor-scan"][pl["bound_mode"]], "batches": pl["batches"],
                     "lanes_per_query": pl["lanes_per_query"], "tail_iter": st["tail_iter"]}}
     if generic:
         rng = np.random.default_rng(11)
@@ -462,7 +462,7 @@ def first_optimisation(name, P, local_rank, callbacks=30, seed=5):
             "set_points_and_create_ms": 1e3 * t_set, "first_callback_ms": per[0], "second_callback_ms": per[1],
             "mean_callback_ms": float(np.mean(per)), "steady_callback_ms": float(np.mean(per[-10:])),
             "callbacks_until_plan_settled": settled_at,
-            "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan"][pl["bound_mode"]], "batches": pl["batches"],
+            "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan", "anchor-scan"][pl["bound_mode"]], "batches": pl["batches"],
                      "lanes_per_query": pl["lanes_per_query"]},
             "note": "wall time of svsdf_create + svsdf_set_points + 30 costFunctionLmbmParallel calls with x * (1 + 1e-3 N(0,1)) "
                     "each (generic piece durations: the reference-faithful piece time runs from the first call on); the plan "

@@ -185,7 +185,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   }
   if (const char *e = std::getenv("SVSDF_CULL")) { ctx->cull = std::atoi(e) != 0; ctx->cull2 = std::atoi(e) >= 2; }   // 0 none, 1 circle bound only, 2 both (default)
   if (const char *e = std::getenv("SVSDF_TAIL")) ctx->tail_mode = (std::string(e) == "off") ? -2 : (std::string(e) == "auto") ? -1 : std::max(0, std::atoi(e));
-  if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_lazy = std::atoi(e) == 2; ctx->ub_env = true; }
+  if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_lazy = std::atoi(e) == 2; ctx->ub_anchor = std::atoi(e) == 3; ctx->ub_env = true; }
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_PIECE_TIME")) {   // exact | fast | auto (default)
     ctx->cfg.flags &= ~(SVSDF_FLAG_EXACT_PIECE_TIME | SVSDF_FLAG_FAST_PIECE_TIME);
@@ -452,18 +452,18 @@ int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]) {
 int svsdf_get_plan(const svsdf_ctx *ctx, svsdf_plan *out) {
   if (!ctx || !out) return SVSDF_ERR_INVALID;
   const svsdf_ctx *c = ctx->subs.empty() ? ctx : ctx->subs[0];
-  out->bound_mode = c->ub_full ? (c->ub_lazy ? 2 : 1) : 0;
+  out->bound_mode = bound_mode_of(c);
   out->batches = (c->saved_nbatch > 0) ? c->saved_nbatch : c->nbatch;
   out->lanes_per_query = c->G;
   out->tail_iter = (c->tail_mode == -2) ? -2 : (c->tail_mode >= 0) ? c->tail_mode : (c->have_prev_nactive ? choose_tail_iter(c) : SVSDF_PLAN_AUTO);
-  out->settled = ((c->ub_env || c->ub_tune > 0) && c->bt_state == 0 && c->have_prev_nsolve) ? 1 : 0;
+  out->settled = ((c->ub_env || c->ub_tune > 0) && c->bt_state == 0 && c->an_state == 0 && c->have_prev_nsolve) ? 1 : 0;
   return SVSDF_OK;
 }
 
 int svsdf_set_plan(svsdf_ctx *ctx, const svsdf_plan *plan) {
   if (!ctx || !plan) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_plan: null argument");
   const int g = plan->lanes_per_query;
-  if (plan->bound_mode < SVSDF_PLAN_AUTO || plan->bound_mode > 2 || plan->batches < -2 || plan->batches == 0 || plan->batches > kMaxBatches ||
+  if (plan->bound_mode < SVSDF_PLAN_AUTO || plan->bound_mode > 3 || plan->batches < -2 || plan->batches == 0 || plan->batches > kMaxBatches ||
       !(g == SVSDF_PLAN_AUTO || g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) || plan->tail_iter < -2 || plan->tail_iter >= kMaxIter)
     return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_plan: field out of range");
   if (!ctx->subs.empty()) {
@@ -477,9 +477,9 @@ int svsdf_set_plan(svsdf_ctx *ctx, const svsdf_plan *plan) {
   if (plan->bound_mode == SVSDF_PLAN_AUTO) {
     if (ctx->ub_env) { ctx->ub_env = false; ctx->ub_tune = 0; ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }
   } else {
-    const bool full = plan->bound_mode != 0, lazy = plan->bound_mode == 2;
-    if (!ctx->ub_env || full != ctx->ub_full || lazy != ctx->ub_lazy) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; ctx->ub_tune = 0; }
-    ctx->ub_env = true; ctx->ub_full = full; ctx->ub_lazy = lazy;
+    const bool full = plan->bound_mode != 0, lazy = plan->bound_mode == 2, anchor = plan->bound_mode == 3;
+    if (!ctx->ub_env || full != ctx->ub_full || lazy != ctx->ub_lazy || anchor != ctx->ub_anchor) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; ctx->ub_tune = 0; }
+    ctx->ub_env = true; ctx->ub_full = full; ctx->ub_lazy = lazy; ctx->ub_anchor = anchor; ctx->an_state = 0;
   }
   ctx->want_batches = (plan->batches == SVSDF_PLAN_AUTO) ? 0 : (plan->batches == -2) ? -1 : plan->batches;
   ctx->bt_state = 0;

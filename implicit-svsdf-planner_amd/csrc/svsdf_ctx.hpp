@@ -119,6 +119,9 @@ struct svsdf_ctx {
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
   bool ub_lazy = false;        // with ub_full: only the samples in the cheap-bound band are scanned (k_round MODE 2)
+  bool ub_anchor = false;      // with ub_full && !ub_lazy: anchor scans (k_round MODE 3: every third sample, the rest by their Lipschitz bound)
+  int an_state = 0;            // anchor trial: 0 decided / idle, 1 next evaluation counts the full mode's table evaluations, 2 the anchor mode's
+  unsigned long long an_full_evals = 0;
   bool ub_env = false;         // env SVSDF_UB_FULL=0/1/2 pins the mode, otherwise run_pipeline decides after one evaluation
   int ub_tune = 0;             // evaluations since the point set changed that took part in the decision (0 or 1)
   double ub_ratio = 0.0;       // GSIP solves / GSIP samples of the deciding (cheap-bound) evaluation
@@ -237,6 +240,7 @@ int dev_alloc(svsdf_ctx *ctx, T **p, size_t count) {
 // throughput (narrow groups waste fewer lanes; the descent's ladders share the wave anyway).  Crossovers re-measured in
 // round 4 after the shared ladders (profiles/r04_lanes_sweep.txt: 100 k points 8 -> 4 lanes - 5 %, 200 k 8 -> 2 lanes - 7 %).
 // (Polygon: never below 4 -- its 2-lane kernel spills under the 3-waves register cap.)
+inline int bound_mode_of(const svsdf_ctx *c) { return c->ub_full ? (c->ub_lazy ? 2 : (c->ub_anchor ? 3 : 1)) : 0; }
 inline int default_lanes(const svsdf_ctx *ctx, size_t Ps) {
   const int g = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 75000) ? 8 : (Ps < 150000) ? 4 : 2;
   return (ctx->cfg.shape_id == (int)svsdf::kPolygon) ? std::max(g, 4) : g;

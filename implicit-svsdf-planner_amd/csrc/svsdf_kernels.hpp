@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           const double qx = cx + 1.0 * r * cos(theta);
           const double qy = cy + 1.0 * r * sin(theta);
           sqx_l[ps] = qx; sqy_l[ps] = qy;
-          if constexpr (MODE != 1) {
+          if constexpr (MODE == 0 || MODE == 2) {
             // cheap upper bound: best table pose of the chunk with the nearest centre (any chunk is valid)
             double d2min = 1e300;
             int c0 = 0;
@@ -1586,7 +1586,107 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         }
       }
       SVSDF_PHASE(rc, 2, tph);
-      if constexpr (FULL) {
+      if constexpr (MODE == 3) {
+        // Anchor scans (round 4; MODE 3 = the full-scan mode with this first stage).  The table minimum ub(q) = min_k sdf_k(q) is 1-Lipschitz in q (a minimum of exact
+        // distance functions), so a scanned sample a bounds its neighbours:  g_j <= ub(q_j) <= ub(q_a) + |q_j - q_a|.
+        // Every third sample of a round with more than 6 is scanned first (the anchors); a sample whose bound from its
+        // neighbour anchors stays more than the selection band below the best anchor cannot be requested now and is not
+        // scanned at all -- it keeps the Lipschitz bound (a valid upper bound: closing the round still requests it if
+        // the solved values fall that low; its solve then scans itself, sq_k = -1).  The others are scanned in a second
+        // pass, and so on until no unscanned sample reaches the band.  On a circle of radius r the bound is loose by
+        // 0.3 r .. 0.6 r: the samples on the far side of the circle from the round's maximum drop out (C3: 5.5 M ->
+        // about half the scans).  Same requests for the samples that matter, same results (any selection is exact).
+        constexpr int SG = LP / 8;
+        const int sg = l >> 3;
+        const int pos3 = (l & 7) % 3;                       // position between anchors inside the 8-lane run of a pass
+        bool scanned[NP], pend[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) { scanned[ps] = false; kk[ps] = -1; pend[ps] = valid[ps] && (n_emit <= 6 || pos3 == 0); }
+        double u2 = -1e300;   // best scanned bound so far
+        for (int rep = 0; rep < 8; ++rep) {
+          unsigned mp[NP];
+          int myrank[NP];
+          int nb = 0;
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) {
+            mp[ps] = ballot_g(pend[ps]);
+            myrank[ps] = nb + __popc(mp[ps] & lt_mask);
+            nb += __popc(mp[ps]);
+          }
+          if (nb == 0) break;
+          for (int p = 0; p * SG < nb; ++p) {
+            const int r = p * SG + sg;          // rank (among the pending samples) this 8-lane sub-group scans
+            int rr = r, sps = 0, sl = 0;
+            bool found = false;
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const int c = __popc(mp[ps]);
+              if (!found && r < nb && rr < c) {
+                unsigned m = mp[ps];
+                for (int q = 0; q < rr; ++q) m &= m - 1u;
+                sl = __ffs(m) - 1;
+                sps = ps;
+                found = true;
+              } else if (!found) {
+                rr -= c;
+              }
+            }
+            double sxs = sqx_l[0], sys = sqy_l[0];
+#pragma unroll
+            for (int ps = 1; ps < NP; ++ps)
+              if (sps == ps) { sxs = sqx_l[ps]; sys = sqy_l[ps]; }
+            const double qx = __shfl(sxs, sl, LP), qy = __shfl(sys, sl, LP);
+            double bd = -1e300;
+            int bk = 0;
+            if (found) {
+              bool cu;
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1);
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const bool mine = pend[ps] && (myrank[ps] / SG == p);
+              const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
+              const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
+              if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
+            }
+          }
+          if (rep == 0 && n_emit > 6) {
+            // bounds of the samples between the anchors: left anchor (always there), right anchor (same 8-lane run)
+            const int la = l - pos3, ra = la + 3;
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const double ul = __shfl(ub[ps], la, LP), xl = __shfl(sqx_l[ps], la, LP), yl = __shfl(sqy_l[ps], la, LP);
+              const int rsrc = ((ra & 7) > (l & 7) && ra < LP) ? ra : la;   // (no right anchor in this run: the left one again)
+              const double ur = __shfl(ub[ps], rsrc, LP), xr = __shfl(sqx_l[ps], rsrc, LP), yr = __shfl(sqy_l[ps], rsrc, LP);
+              const bool rv = __shfl((int)(valid[ps] && scanned[ps]), rsrc, LP) != 0;
+              if (valid[ps] && !scanned[ps]) {
+                double b = ul + norm2(sqx_l[ps] - xl, sqy_l[ps] - yl);
+                if (rv) b = dmin(b, ur + norm2(sqx_l[ps] - xr, sqy_l[ps] - yr));
+                ub[ps] = b + 1e-9;
+              }
+            }
+          }
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) u2 = scanned[ps] ? fmax(u2, ub[ps]) : u2;
+          u2 = fmax(u2, Grp<LP>::template xchg<0>(u2));
+          u2 = fmax(u2, Grp<LP>::template xchg<1>(u2));
+          u2 = fmax(u2, Grp<LP>::template xchg<2>(u2));
+          if constexpr (LP == 32) {
+            u2 = fmax(u2, Grp<LP>::template xchg<3>(u2));
+            u2 = fmax(u2, Grp<LP>::template xchg<4>(u2));
+          }
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) pend[ps] = valid[ps] && !scanned[ps] && ub[ps] >= u2 - delta;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+          if (valid[ps]) {
+            const size_t s = sample_slot(stride, ia, l + LP * ps);
+            gs.sq_ub[s] = ub[ps];
+            gs.sq_k[s] = kk[ps];
+            if (!scanned[ps]) ub[ps] = -1e300;   // only scanned samples take part in the selection below
+          }
+      } else if constexpr (MODE == 1) {
         // Tightest bound layer 1 can give: the sample's own seed (the full pruned scan its solve would start
         // with), found here by 8 cooperating lanes per sample -- LP / 8 samples at a time -- and handed to
         // k_solve, which then skips its scan.  For shapes / trajectories where the nearest chunk is a poor
@@ -1754,7 +1854,8 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #endif
 constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
 // MODE: 0 cheap bound (nearest chunk), 1 full (every new sample scanned), 2 lazy (cheap bound for all, the sample's own
-// table scan only for those within `band_delta` of the best cheap bound -- the ones the cheap mode would solve)
+// table scan only for those within `band_delta` of the best cheap bound -- the ones the cheap mode would solve), 3 anchor
+// (every third sample scanned, the others only if their Lipschitz bound from the anchors reaches the selection band)
 template <int SHAPE, int LP, int MODE>
 __global__ void __launch_bounds__(kRoundBlock)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,

@@ -150,7 +150,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
 }
 
 void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
-  const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;   // k_round MODE: cheap / full / lazy bound
+  const int mode = bound_mode_of(ctx);   // k_round MODE: cheap / full / lazy / anchor bound
   const bool scans = mode != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
   bool poly_lds = ctx->poly_lds;
@@ -192,7 +192,7 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
 
 // k_tail: every GSIP iteration of batch b from `it0` on, in one launch (two points per wave, solved in the wave).
 void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
-  const int mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
+  const int mode = bound_mode_of(ctx);
   const bool scans = mode != 0;
   const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
   const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
@@ -636,10 +636,10 @@ int evaluate_points(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
 }
 
 void fill_mode_stats(svsdf_ctx *ctx) {
-  ctx->stats.gsip_bound_mode = ctx->ub_full ? (ctx->ub_lazy ? 2 : 1) : 0;
+  ctx->stats.gsip_bound_mode = bound_mode_of(ctx);
   ctx->stats.piece_time_exact = ctx->stats_piece_time;
   ctx->stats.bound_mode_decided = (ctx->ub_env || ctx->ub_tune > 0) ? 1 : 0;
-  ctx->stats.plan_settled = (ctx->stats.bound_mode_decided && ctx->bt_state == 0 && ctx->have_prev_nsolve) ? 1 : 0;
+  ctx->stats.plan_settled = (ctx->stats.bound_mode_decided && ctx->bt_state == 0 && ctx->an_state == 0 && ctx->have_prev_nsolve) ? 1 : 0;
   ctx->stats.bound_ratio = ctx->ub_ratio;
   ctx->stats.n_devices = 1;
   ctx->stats.combine = SVSDF_COMBINE_HOST;
@@ -684,7 +684,14 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   // evaluations per mode with the wall clock; the rule reproduces its choices on C1-C5 without the five extra
   // evaluations and without depending on the box.)
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
-  if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; }
+  if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; ctx->ub_anchor = false; ctx->an_state = 0; }
+  // Anchor trial (full-scan shapes only): one evaluation in the full mode and one in the anchor mode, compared by their
+  // table-evaluation COUNTERS (deterministic: no timing) -- the anchor mode stays when it saves at least 28 % of them
+  // (sdHeart - 32 %: k_round - 27 %, evaluation - 12 %; Polygon - 25 %: a wash; sdHorseshoe - 10 %: + 5 %, its extra passes
+  // cost more than the skipped scans; profiles/r04_anchor_ab.txt).  Both modes return the same bits.
+  const int an_trial = (ctx->ub_env || ctx->saved_nbatch > 0) ? 0 : ctx->an_state;
+  if (an_trial == 1) ctx->ub_anchor = false;
+  if (an_trial == 2) ctx->ub_anchor = true;
   // Batch count (large shards in the scanning modes; DESIGN.md "concurrent point batches").  Default: a RULE -- 3 batches in
   // a scanning bound mode from 400 k points per device, 1 otherwise (what the measurements of rounds 3 - 4 -- 1 / 2 / 3 / 4 at NS, C3, C4 --
   // chose on every box; with the main stream that is at most 4 streams, the HIP runtime's default number of hardware
@@ -718,6 +725,15 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
       }
     }
   }
+  if (rc == SVSDF_OK && an_trial == 1) {
+    ctx->an_full_evals = ctx->stats.round_scan_evals;
+    ctx->an_state = 2;
+  } else if (rc == SVSDF_OK && an_trial == 2) {
+    const bool keep = (double)ctx->stats.round_scan_evals <= 0.72 * (double)ctx->an_full_evals;
+    if (keep != ctx->ub_anchor) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }
+    ctx->ub_anchor = keep;
+    ctx->an_state = 0;
+  }
   if (rc == SVSDF_OK && deciding) {
     const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
     const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
@@ -730,6 +746,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     const bool large = ctx->P >= 400000;
     ctx->ub_full = ctx->ub_ratio > thr || large;
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
+    if (ctx->ub_full && !ctx->ub_lazy) ctx->an_state = 1;   // full scans pay: does the anchor variant pay more?
     if (ctx->ub_full) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }   // the launch plan on record is the cheap-bound one
   }
   // the batch count follows once the bound mode is known (also when it was pinned)
@@ -1015,7 +1032,8 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   ctx->ub_tune = 0;
   ctx->bt_state = 0;
   ctx->ub_ratio = 0.0;
-  if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; }
+  if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; ctx->ub_anchor = false; }
+  ctx->an_state = 0;
   if (!ctx->G_env) {
     // (Polygon: 4 -- its 2-lane kernel spills 52 registers under the 3-waves cap; C5 36.5 vs 34.8 ms)
     ctx->G = default_lanes(ctx, Ps);

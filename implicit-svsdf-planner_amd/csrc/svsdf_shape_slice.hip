@@ -66,9 +66,9 @@ bool round_s(int lp, int mode, unsigned grid, size_t lds, hipStream_t st, const 
                      a.px, a.py, a.gs, a.stride, a.it, a.delta, a.band_delta, a.res_sdf, a.res_t, a.res_gx,          \
                      a.res_gy, a.ctl, a.clist_on)
     if (lp == 8) {
-      if (mode == 2) ROUND(8, 2); else if (mode == 1) ROUND(8, 1); else ROUND(8, 0);
+      if (mode == 3) ROUND(8, 3); else if (mode == 2) ROUND(8, 2); else if (mode == 1) ROUND(8, 1); else ROUND(8, 0);
     } else {
-      if (mode == 2) ROUND(32, 2); else if (mode == 1) ROUND(32, 1); else ROUND(32, 0);
+      if (mode == 3) ROUND(32, 3); else if (mode == 2) ROUND(32, 2); else if (mode == 1) ROUND(32, 1); else ROUND(32, 0);
     }
 #undef ROUND
     return true;
@@ -84,7 +84,7 @@ bool tail_s(int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunc
   hipLaunchKernelGGL((k_tail<S, MODE>), dim3(grid), dim3(kTailBlock), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp,  \
                      a.px, a.py, a.gs, a.stride, a.it0, a.prev_mode, a.delta, a.band_delta, a.all_after, a.ppw, a.res_sdf,   \
                      a.res_t, a.res_gx, a.res_gy, a.ctl, a.clist_on, a.prune)
-    if (mode == 2) TAIL(2); else if (mode == 1) TAIL(1); else TAIL(0);
+    if (mode == 3) TAIL(3); else if (mode == 2) TAIL(2); else if (mode == 1) TAIL(1); else TAIL(0);
 #undef TAIL
     return true;
   }

@@ -354,7 +354,7 @@ typedef struct svsdf_stats {
   unsigned int gsip_iterations;       /* GSIP iterations that had work (rounds + supplementary) */
   unsigned long long culled_points;   /* main queries proven inactive (sdf > safety_hor) without a solve */
   int gsip_bound_mode;                /* 0 = cheap chunk bound, 1 = table scan of every GSIP sample, 2 = lazy: table scan of
-                                         the samples within the selection band of the cheap bound only */
+                                         the samples within the selection band of the cheap bound only, 3 = anchor scans */
   int bound_mode_decided;             /* 1 once the mode is fixed for this point set (after <= 1 evaluation) */
   double bound_ratio;                 /* GSIP solves / samples of the deciding evaluation (rule: > 0.5 -> full) */
   int n_devices;                      /* devices that took part (1 unless svsdf_config::n_devices > 1) */
@@ -393,7 +393,8 @@ int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
  * context; svsdf_get_plan reports what is in force.  Multi-device contexts apply / report per device (get: device 0). */
 #define SVSDF_PLAN_AUTO (-1)
 typedef struct svsdf_plan {
-  int bound_mode;       /* GSIP upper-bound mode: 0 cheap chunk bound, 1 table scan of every sample, 2 lazy; SVSDF_PLAN_AUTO */
+  int bound_mode;       /* GSIP upper-bound mode: 0 cheap chunk bound, 1 table scan of every sample, 2 lazy, 3 anchor scans (every
+                           third sample, the others only if their Lipschitz bound reaches the selection band); SVSDF_PLAN_AUTO */
   int batches;          /* concurrent point batches 1..8; SVSDF_PLAN_AUTO: by rule; -2: measured (three HIP-event timings
                            per candidate count, best median) */
   int lanes_per_query;  /* lanes of the main solve's lane groups: 1, 2, 4, 8, 16, 32; SVSDF_PLAN_AUTO: by shard size */

@@ -39,7 +39,7 @@ def test_fused_tail_is_invisible(built, config, P):
     ref_c.set_plan(tail_iter=-2)
     ref = _all(ref_c, w)
     assert ref_c.stats()["tail_iter"] == -1
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         for ti in (0, 1, 3):
             c = _ctx(w)
             c.set_plan(bound_mode=mode, tail_iter=ti)
@@ -62,14 +62,20 @@ def test_plan_is_deterministic_and_observable(built):
     for _ in range(2):
         c = _ctx(w)
         assert c.get_plan()["settled"] == 0
-        c.eval_penalty(w["coeffs"], w["T"])
+        n = 0
+        while n < 8 and not c.get_plan()["settled"]:     # cheap bound -> full scans -> (anchor trial: two more) -> widths
+            c.eval_penalty(w["coeffs"], w["T"])
+            n += 1
+        assert 2 <= n <= 5, n
         ref = _all(c, w)
         pl = c.get_plan()
         assert pl["settled"] == 1 and c.stats()["plan_settled"] == 1
-        plans.append(pl)
+        plans.append((pl, n))
         c.close()
     assert plans[0] == plans[1], plans
-    assert plans[0]["bound_mode"] == 1 and plans[0]["batches"] == 1 and plans[0]["lanes_per_query"] == 8      # sdHorseshoe: full scans
+    plans = [p_[0] for p_ in plans]
+    # sdHorseshoe: full scans pay, the anchor variant saves too few of them (decided by counters, not by timing)
+    assert plans[0]["bound_mode"] == 1 and plans[0]["batches"] == 1 and plans[0]["lanes_per_query"] == 8
     c = _ctx(w)
     c.set_plan(bound_mode=2, batches=3, lanes_per_query=4, tail_iter=2)
     got = _all(c, w)
@@ -78,7 +84,7 @@ def test_plan_is_deterministic_and_observable(built):
     assert c.stats()["batches"] == 3 and c.stats()["gsip_bound_mode"] == 2 and c.stats()["tail_iter"] == 2
     _same(got, ref, "pinned plan")
     c.set_plan()          # everything back to the rules
-    for _ in range(3):
+    for _ in range(5):
         got = _all(c, w)
     assert c.get_plan() == plans[0], (c.get_plan(), plans[0])
     _same(got, ref, "rules again")
@@ -111,6 +117,29 @@ def test_measured_batch_count_settles(built):
         n += 1
         if c.get_plan()["settled"]:
             break
-    assert c.get_plan()["settled"] == 1 and 10 <= n <= 13, n     # decide + learn + 3 x 3 timed
+    assert c.get_plan()["settled"] == 1 and 10 <= n <= 15, n     # decide (+ anchor trial) + learn + 3 x 3 timed
     assert c.get_plan()["batches"] in (1, 3, 4)
     c.close()
+
+
+def test_anchor_scans_are_chosen_by_counters_and_invisible(built):
+    """sdHeart (BASELINE config 4): full scans pay, and the anchor variant (every third GSIP sample scanned, the others only
+    if their Lipschitz bound from the anchors reaches the selection band) saves a third of the table evaluations -- the
+    library keeps it, by a rule on its own counters; the result is the same bits as the full mode."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make("C4", P=60000, minco=svsdf_amd.minco_coeffs)
+    c = _ctx(w)
+    n = 0
+    while n < 8 and not c.get_plan()["settled"]:
+        c.eval_penalty(w["coeffs"], w["T"])
+        n += 1
+    assert c.get_plan()["bound_mode"] == 3 and n <= 5, (c.get_plan(), n)
+    got = _all(c, w)
+    anchor_evals = c.stats()["round_scan_evals"]
+    f = _ctx(w)
+    f.set_plan(bound_mode=1)
+    ref = _all(f, w)
+    assert f.stats()["gsip_bound_mode"] == 1 and anchor_evals <= 0.72 * f.stats()["round_scan_evals"]
+    _same(got, ref, "anchor vs full")
+    c.close(); f.close()
