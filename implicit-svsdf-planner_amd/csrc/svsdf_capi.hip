@@ -167,7 +167,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     sp.nverts = (int)(v.size() / 2);
     sp.accel = reinterpret_cast<const PolyAccel *>(ctx->d_poly);
     sp.edges = pa.hdr.edges;
-    // the solve / round kernels keep outlines of up to 1024 edges (40 KB) in LDS in front of the pose table
+    // the solve / round kernels keep outlines of up to 1024 edges (48 KB) in LDS in front of the pose table
     ctx->poly_lds = sp.nverts <= kPolyLdsMaxVerts;
     if (const char *e = std::getenv("SVSDF_POLY_LDS")) ctx->poly_lds = ctx->poly_lds && std::atoi(e) != 0;
     ctx->cfg.polygon_nverts = sp.nverts;

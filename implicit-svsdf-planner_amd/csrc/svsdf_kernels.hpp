@@ -123,14 +123,14 @@ __device__ __forceinline__ TrajL stage_traj(const TrajDev *__restrict__ g, doubl
   return tr;
 }
 
-// kPolygonLds kernels: copy the outline's edges (5 doubles each) to the START of the block's dynamic LDS (shape_sdf reads
+// kPolygonLds kernels: copy the outline's edges (6 doubles each) to the START of the block's dynamic LDS (shape_sdf reads
 // them from there, svsdf_shapes.hpp); the kernel's other LDS tables follow at poly_lds_doubles<SHAPE>(nverts).  Call
 // before the block's first __syncthreads.
 template <int SHAPE>
 __device__ __forceinline__ void stage_poly_edges(const ShapeParams &sp, double *lds) {
   if constexpr (SHAPE == kPolygonLds) {
     const double *src = reinterpret_cast<const double *>(sp.edges);
-    for (int i = threadIdx.x; i < 5 * sp.nverts; i += blockDim.x) lds[i] = src[i];
+    for (int i = threadIdx.x; i < kPolyEdgeDoubles * sp.nverts; i += blockDim.x) lds[i] = src[i];
   }
 }
 
@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
 //    accepts (bit-identical result, shorter dependent chain).  getSDF_DOT (SWM:799-806) is
 //    evaluated once per descent pass: x does not change inside the ladder, so the reference's
 //    per-trial re-evaluation returns the same number.
-// LDS: [Polygon edges 5 nverts (kPolygonLds only) | pose table 4K | chunks 4*nch | trajectory 20N+1] doubles, then
+// LDS: [Polygon edges 6 nverts (kPolygonLds only) | pose table 4K | chunks 4*nch | trajectory 20N+1] doubles, then
 // ladder_lds_bytes(G) per wave of the block (descent state of its 64 / G groups).
 // ---------------------------------------------------------------------------------------------
 // (Polygon: 172 VGPRs would mean 2 waves per SIMD for a kernel that waits on its candidate-record loads; asking for 3

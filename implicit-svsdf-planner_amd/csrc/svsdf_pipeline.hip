@@ -120,7 +120,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
   size_t lds = 0, lds_total = 0;
   int blk = ctx->block;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
+    lds = (table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? (size_t)svsdf::kPolyEdgeDoubles * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
     blk = ctx->block;
     if (!ctx->block_env) blk = ((lds + wlds) * 12 <= 160 * 1024) ? 64 : ((lds + 2 * wlds) * 6 <= 160 * 1024) ? 128 : 256;
     lds_total = ((lds + 15) & ~(size_t)15) + (size_t)(blk / 64) * wlds;
@@ -154,7 +154,7 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const bool scans = mode != 0;
   const long long pts = std::max(1, ctx->bcount[b]);
   bool poly_lds = ctx->poly_lds;
-  size_t lds = (table_lds_doubles(ctx) + (poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
+  size_t lds = (table_lds_doubles(ctx) + (poly_lds ? (size_t)svsdf::kPolyEdgeDoubles * (size_t)ctx->sp.nverts : 0)) * sizeof(double);
   if (lds + 16384 > ctx->lds_limit && poly_lds) {   // (k_round's static tables: < 16 KB) edges from global memory instead
     poly_lds = false;
     lds = table_lds_doubles(ctx) * sizeof(double);
@@ -205,7 +205,7 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   bool poly_lds = ctx->poly_lds;
   size_t lds = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? 5 * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
+    const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? (size_t)svsdf::kPolyEdgeDoubles * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
     lds = lds_tables + (kTailBlock / 64) * kTailWaveLds;
     if (lds <= ctx->lds_limit || !poly_lds) break;
     poly_lds = false;

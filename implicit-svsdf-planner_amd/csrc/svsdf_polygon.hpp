@@ -6,21 +6,34 @@
 // atan2-based crossing test against the +x ray (isCrossRayOnXDir, SHP:1370-1383).  This file evaluates the same value,
 // bit for bit, from candidate lists built once per outline on the host:
 //
-//   distance  two uniform grids in the body frame (a fine one around the outline, a coarse one out to ~3 shape
-//             sizes).  A cell lists, in ascending edge order, every edge that can be the nearest one for SOME point of
-//             the (slightly enlarged) cell:  lb_e <= U,  lb_e = exact distance cell <-> edge,  U = min over edges of
-//             the largest corner-to-edge distance (distance to a segment is convex, so that is its maximum over the
-//             cell).  An edge that is not listed is farther than the nearest listed one by a margin (1e-9) far above
-//             the rounding of the per-edge arithmetic, so the minimum over the listed edges is the minimum over all
-//             edges: the same double the reference's loop ends with.  Points outside both grids take the full loop.
-//   parity    horizontal slabs over the outline's y-range; a slab lists the edges whose y-range (enlarged by `tol`)
-//             meets it.  An edge with both end points on one side of the query's ray line by more than the rounding
-//             of two atan2 calls can never satisfy |theta_s - theta_e| >= PI (both angles strictly inside (0, PI) or
-//             (PI, 2 PI)), so only the listed edges are put through the reference's test; a query above / below the
-//             outline or to the right of it (x > xmax + tol: every angle in (PI/2, 3 PI/2)) counts no crossing.
+//   distance  three uniform grids in the body frame: a fine one around the outline, a coarse one out to ~3 shape sizes,
+//             a far one out to 40 (beyond that: all edges).  A cell lists, in ascending edge order, every edge that can
+//             be the nearest one for SOME point of the (slightly enlarged) cell.  First pass (fine, coarse):  lb_e <= U,
+//             lb_e = exact distance cell <-> edge,  U = min over edges of the largest corner-to-edge distance (distance
+//             to a segment is convex, so that is its maximum over the cell).  Second pass (and the only one of the far
+//             grid, run down a pyramid of grids): sample points, each standing for a sub-rectangle of half diagonal rho;
+//             with e* the nearest edge at the sample c, an edge e stays iff  d(c, e) - d(c, e*) <= lip rho,  lip =
+//             min(2, diam(e u e*) / (d(c, e*) - rho)) bounding |grad (d_e - d_e*)| = the difference of the two unit
+//             directions: far from a rounded corner its short edges are all nearly equidistant but their bisectors fan
+//             out.  An edge that is not listed is farther than the nearest listed one by a margin (1e-9) far above the
+//             rounding of the per-edge arithmetic, so the minimum over the listed edges is the minimum over all edges:
+//             the same double the reference's loop ends with.
+//   parity    a cell that stays clear of the outline knows the parity of the crossing count of all its queries (the
+//             reference's test only depends on rounding within ~1e-15 of an edge); a cell the outline passes through
+//             carries its own crossing candidates in the upper half of its record (plus the parity of the edges that
+//             cross every ray of the cell); what does not fit, and a query outside the grids, uses horizontal slabs x
+//             buckets of x over the outline's bounding box: a slab lists the edges whose y-range (enlarged by `tol`)
+//             meets it and that are not entirely to the left of the bucket.  An edge with both end points on one side
+//             of the query's ray line by more than the rounding of two atan2 calls can never satisfy
+//             |theta_s - theta_e| >= PI, so only the listed edges are put through the reference's test; a query above /
+//             below the outline or to the right of it counts no crossing.
 //
-// The per-edge arithmetic is the reference's, operation for operation (true division, no contraction; v = end - start
-// and v.squaredNorm() are the same IEEE operations whether done here per evaluation or once on the host).
+// The per-edge arithmetic is the reference's, operation for operation, except that the quotient of dis2Seg is obtained
+// from the edge's reciprocal by two residual steps that provably end in the division's own rounding (poly_quot); no
+// contraction; v = end - start and v.squaredNorm() are the same IEEE operations whether done here per evaluation or once
+// on the host.  A wave walks its lanes' lists in step (poly_for_each); a lane the fast path cannot serve (a list longer
+// than its record, an operand outside poly_quot's range, a crossing angle within 1e-9 rad of 0 or pi, a query outside
+// all grids) re-evaluates on its own with the division and the reference's atan2 formula.
 // __host__ __device__: tests/cpp/poly_host.cpp runs the very same functions on the CPU against the oracle's plain loop.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -31,13 +44,17 @@
 
 namespace svsdf {
 
-struct PolyEdge { double sx, sy, vx, vy, vv; };   // start, v = end - start, v.squaredNorm(); the end is the next edge's start
+// rv = 1 / vv, correctly rounded (host): the quotient of dis2Seg is refined from it (poly_quot)
+struct alignas(16) PolyEdge { double sx, sy, vx, vy, vv, rv; };   // start, v = end - start, v.squaredNorm(); the end is the next edge's start
+constexpr int kPolyEdgeDoubles = 6;
 
-// A candidate list in one 32-byte record of 16-bit words: [0] = count; count <= 15: [1 .. count] = the edges, ascending;
-// count > 15: [1] | [2] << 16 = offset of the list in `over`.  One 32-byte load gives a query its whole list in registers
-// (the evaluation walks it with shifts: no dependent load per edge).
+// A candidate list in one 32-byte record of 16-bit words h[0 .. 15]: h[15] = count | parity state << 14; count <= 15:
+// h[0 .. count - 1] = the edges, ascending; count > 15: h[0] | h[1] << 16 = offset of the list in `over`.  One 32-byte
+// load gives a query its whole list in registers (no dependent load per edge).  Parity state (distance records of grid
+// cells only): 0 = run the crossing test, 1 = every query of the cell is outside (even crossings), 2 = inside.
 struct alignas(32) PolyRec { unsigned w[8]; };
 constexpr int kPolyInline = 15;
+constexpr unsigned kPolyCountMask = 0x1fffu;   // counts up to kPolyMaxVerts = 4096
 
 struct PolyLevel {
   double x0, y0, inv_h;   // cell (ix, iy) = floor((x - x0) * inv_h), floor((y - y0) * inv_h)
@@ -50,28 +67,44 @@ struct PolyAccel {
   int n;                         // edges = vertices
   int nslab;
   const PolyEdge *edges;
-  const PolyRec *cells;          // candidate edges per grid cell (both levels)
-  const PolyRec *slabs;          // candidate edges per parity slab
+  const PolyRec *cells;          // candidate edges per grid cell (both levels) + the cell's parity state
+  const PolyRec *slabs;          // crossing-parity candidates per (slab of y, bucket of x): nslab * nxb records
   const unsigned short *over;    // lists longer than kPolyInline
-  PolyLevel lv[2];               // 0 fine, 1 coarse
+  PolyLevel lv[3];               // 0 fine (around the outline), 1 coarse (to 3 shape sizes), 2 far (to 40 shape sizes)
   double ymin, ymax, xmax, tol, slab_inv_h;
+  double xmin, xb_inv_h;         // x buckets of the parity lists: [xmin, xmax] in nxb buckets (left of xmin: bucket 0)
+  int nxb;
+  int div_ok;                    // every edge's vv in [1e-100, 1e100]: poly_quot may refine instead of dividing
 };
 
+#ifndef SVSDF_POLY_REFINE
+#define SVSDF_POLY_REFINE 2   // sample points per cell side in the second pass of the candidate lists (0 = off)
+#endif
 constexpr int kPolyMaxVerts = 4096;   // = SVSDF_MAX_POLY_VERTS (16-bit edge indices; host build time)
+
+// true when the condition holds in any lane of the wave (the host build has one lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SVSDF_WAVE_ANY(c) (__any((int)(c)) != 0)
+#else
+#define SVSDF_WAVE_ANY(c) (c)
+#endif
 
 // isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
 // atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
 // opposite signs of y and the vector with y > 0 leading the other by more than pi counter-clockwise, i.e.
 // sign(cross(s2, e2)) -- decided without atan2 unless the angle difference is within ~1e-9 rad of 0 or pi
 // (sin^2 <= 1e-18), where the rounding of the two atan2 values (~1e-16) could matter and the reference
-// formula itself is evaluated.
-__host__ __device__ __forceinline__ bool poly_cross_ray(double s2x, double s2y, double e2x, double e2y) {
+// formula itself is evaluated.  poly_cross_fast: the decision when it is certain (returns false: not certain).
+__host__ __device__ __forceinline__ bool poly_cross_fast(double s2x, double s2y, double e2x, double e2y, bool &cross) {
   const double crs = s2x * e2y - s2y * e2x;
   const double n2 = (s2x * s2x + s2y * s2y) * (e2x * e2x + e2y * e2y);
-  if (s2y != 0.0 && e2y != 0.0 && crs * crs > 1e-18 * n2) {
-    const bool sneg = s2y < 0.0, eneg = e2y < 0.0;
-    return (sneg != eneg) && ((crs < 0.0) == eneg);
-  }
+  const bool sneg = s2y < 0.0, eneg = e2y < 0.0;
+  cross = (sneg != eneg) & ((crs < 0.0) == eneg);
+  return (s2y != 0.0) & (e2y != 0.0) & (crs * crs > 1e-18 * n2);
+}
+__host__ __device__ inline bool poly_cross_ray(double s2x, double s2y, double e2x, double e2y) {
+  bool cross;
+  if (poly_cross_fast(s2x, s2y, e2x, e2y, cross)) return cross;
   const double PI_ = 3.14159265358979323846;   // SHP:31
   double theta_s = atan2(s2y, s2x);
   double theta_e = atan2(e2y, e2x);
@@ -80,10 +113,31 @@ __host__ __device__ __forceinline__ bool poly_cross_ray(double s2x, double s2y, 
   return !(fabs(theta_s - theta_e) < PI_);
 }
 
-// dis2Seg (SHP:1385-1401) up to the closest point c; returns |p - c|^2 (the reference takes its root)
-__host__ __device__ __forceinline__ double poly_edge_d2(const PolyEdge &e, double x, double y, double &cx, double &cy) {
+// a / b as the division rounds it, from rb = RN(1 / b): q0 = RN(a rb) is within 2 ulp, one residual step
+// (r = a - q b exactly, q += r rb) leaves it within 1 ulp, and from there the same step gives RN(a / b) (Markstein's
+// theorem: correctly rounded reciprocal + faithful quotient).  Five full-rate operations instead of the division's
+// thirteen (one of them the quarter-rate v_rcp_f64).  Valid while nothing can over- or underflow: b in [1e-100, 1e100]
+// (PolyAccel::div_ok, checked once on the host) and |a| in [1e-150, 1e150] -- `inrange`; a query that ever leaves that
+// range (a zero, a NaN) is re-evaluated with the division itself (poly_sdf's second path).
+// tests/test_polygon_accel.py compares it with the division on adversarial operands.
+__host__ __device__ __forceinline__ double poly_quot(double a, double b, double rb, bool &inrange) {
+  const double fa = fabs(a);
+  inrange = (fa >= 1e-150) & (fa <= 1e150);
+  double q = a * rb;
+  double r = __builtin_fma(-q, b, a);
+  q = __builtin_fma(r, rb, q);
+  r = __builtin_fma(-q, b, a);
+  return __builtin_fma(r, rb, q);
+}
+
+// dis2Seg (SHP:1385-1401) up to the closest point c; returns |p - c|^2 (the reference takes its root).
+// FAST: the quotient from the edge's reciprocal (poly_quot), `inrange` says whether it may be used.
+template <bool FAST>
+__host__ __device__ __forceinline__ double poly_edge_d2(const PolyEdge &e, double x, double y, double &cx, double &cy, bool &inrange) {
   const double wx = x - e.sx, wy = y - e.sy;
-  double t = (wx * e.vx + wy * e.vy) / e.vv;
+  double t;
+  if constexpr (FAST) t = poly_quot(wx * e.vx + wy * e.vy, e.vv, e.rv, inrange);
+  else { t = (wx * e.vx + wy * e.vy) / e.vv; inrange = true; }
   t = (t < 0.0) ? 0.0 : ((t > 1.0) ? 1.0 : t);   // if (t < 0) t = 0; else if (t > 1) t = 1;  (a NaN stays a NaN)
   cx = e.sx + t * e.vx;
   cy = e.sy + t * e.vy;
@@ -98,41 +152,58 @@ __host__ __device__ __forceinline__ int poly_cell(const PolyLevel &lv, double x,
   return (int)fy * lv.nx + (int)fx;
 }
 
-// Walk the candidate list of a record in ascending order: f(edge index, edge, start of the next edge).  The list sits in
-// registers (shifted out 16 bits at a time) or, when longer than kPolyInline, in `over`; the edge of step k + 1 is
-// loaded while step k computes (the loop is a dependent chain of loads otherwise).  NEXT: also the following edge's
-// start = this edge's end (crossing test).
+// the innermost grid level that holds (x, y): its cell and the level's first record; -1 outside all three
+__host__ __device__ __forceinline__ int poly_locate(const PolyAccel &pa, double x, double y, unsigned &base) {
+  int cell = poly_cell(pa.lv[0], x, y);
+  base = pa.lv[0].base;
+  if (cell < 0) { cell = poly_cell(pa.lv[1], x, y); base = pa.lv[1].base; }
+  if (cell < 0) { cell = poly_cell(pa.lv[2], x, y); base = pa.lv[2].base; }
+  return cell;
+}
+
+__host__ __device__ __forceinline__ unsigned poly_count(const PolyRec &rec) { return (rec.w[7] >> 16) & kPolyCountMask; }
+
+// edge k of a record's list (a lane's own walk; the wave's walk below never shifts through the record like this)
+__host__ __device__ __forceinline__ unsigned poly_list_index(const PolyRec &rec, const unsigned short *over, unsigned cnt, unsigned k) {
+  if (cnt > (unsigned)kPolyInline) return over[rec.w[0] + k];
+  const unsigned j = k >> 1;
+  const unsigned wk = (j == 0u) ? rec.w[0] : (j == 1u) ? rec.w[1] : (j == 2u) ? rec.w[2] : (j == 3u) ? rec.w[3]
+                    : (j == 4u) ? rec.w[4] : (j == 5u) ? rec.w[5] : (j == 6u) ? rec.w[6] : rec.w[7];
+  return (k & 1u) ? (wk >> 16) : (wk & 0xffffu);
+}
+
+// The WAVE walks the (inline) candidate lists of its lanes in step, ascending: f(valid, edge, start of the next edge).
+// The trip count is the longest list among the lanes (a scalar branch, no exec-mask bookkeeping per edge), two edges per
+// step out of one word of the record, and a lane whose list has ended (or is empty: cnt = 0) repeats its first edge
+// with valid = false.  No lane-dependent branch anywhere in the body.
+// NEXT: also the following edge's start = this edge's end (crossing test).
 template <bool NEXT, typename F>
-__host__ __device__ __forceinline__ void poly_for_each(const PolyRec &rec, const unsigned short *over, const PolyEdge *edges,
-                                                       int n, F &&f) {
-  unsigned w0 = rec.w[0], w1 = rec.w[1], w2 = rec.w[2], w3 = rec.w[3], w4 = rec.w[4], w5 = rec.w[5], w6 = rec.w[6], w7 = rec.w[7];
-  const unsigned cnt = w0 & 0xffffu;
-  if (cnt == 0u) return;
-  const bool inl = cnt <= (unsigned)kPolyInline;
-  const unsigned off = (w0 >> 16) | (w1 << 16);
-  auto funnel = [](unsigned hi, unsigned lo) -> unsigned { return (lo >> 16) | (hi << 16); };   // v_alignbit_b32
-  auto next_index = [&](unsigned k) -> unsigned {
-    if (inl) {   // next 16-bit word of the 256-bit record
-      w0 = funnel(w1, w0); w1 = funnel(w2, w1); w2 = funnel(w3, w2); w3 = funnel(w4, w3);
-      w4 = funnel(w5, w4); w5 = funnel(w6, w5); w6 = funnel(w7, w6); w7 >>= 16;
-      return w0 & 0xffffu;
-    }
-    return over[off + k];
+__host__ __device__ __forceinline__ void poly_for_each(const PolyRec &rec, unsigned cnt, const PolyEdge *edges, int n, F &&f) {
+  if (!SVSDF_WAVE_ANY(cnt != 0u)) return;
+  auto next_start = [&](unsigned idx, double &nsx, double &nsy) {
+    const PolyEdge &nx = edges[(idx + 1u == (unsigned)n) ? 0u : idx + 1u];
+    nsx = nx.sx; nsy = nx.sy;
   };
-  unsigned idx = next_index(0);
-  PolyEdge cur = edges[idx];
-  double nsx = 0.0, nsy = 0.0;
-  if constexpr (NEXT) { const PolyEdge &nx = edges[(idx + 1u == (unsigned)n) ? 0u : idx + 1u]; nsx = nx.sx; nsy = nx.sy; }
-  for (unsigned k = 0; k < cnt; ++k) {
-    const PolyEdge e = cur;
-    const double ex = nsx, ey = nsy;
-    const int i = (int)idx;
-    if (k + 1u < cnt) {
-      idx = next_index(k + 1u);
-      cur = edges[idx];
-      if constexpr (NEXT) { const PolyEdge &nx = edges[(idx + 1u == (unsigned)n) ? 0u : idx + 1u]; nsx = nx.sx; nsy = nx.sy; }
-    }
-    f(i, e, ex, ey);
+  const unsigned first = (cnt != 0u) ? (rec.w[0] & 0xffffu) : 0u;
+  auto pair = [&](unsigned wj, unsigned k) {   // edges k, k + 1 of the list = the two halves of word k / 2
+    const bool v0 = k < cnt, v1 = k + 1u < cnt;
+    const unsigned i0 = v0 ? (wj & 0xffffu) : first, i1 = v1 ? (wj >> 16) : first;
+    const PolyEdge e0 = edges[i0], e1 = edges[i1];
+    double e0x = 0.0, e0y = 0.0, e1x = 0.0, e1y = 0.0;
+    if constexpr (NEXT) { next_start(i0, e0x, e0y); next_start(i1, e1x, e1y); }
+    f(v0, e0, e0x, e0y);
+    f(v1, e1, e1x, e1y);
+  };
+  // the record as four 64-bit words, moved down one word every four edges (three 64-bit moves)
+  unsigned long long q0 = rec.w[0] | ((unsigned long long)rec.w[1] << 32), q1 = rec.w[2] | ((unsigned long long)rec.w[3] << 32),
+                     q2 = rec.w[4] | ((unsigned long long)rec.w[5] << 32), q3 = rec.w[6] | ((unsigned long long)rec.w[7] << 32);
+#pragma nounroll   // (peeled and unrolled it is 16 copies of the body at each of a kernel's dozen evaluation sites)
+  for (unsigned k = 0;; k += 4u) {
+    pair((unsigned)q0, k);
+    if (!SVSDF_WAVE_ANY(k + 2u < cnt)) break;
+    pair((unsigned)(q0 >> 32), k + 2u);
+    if (!SVSDF_WAVE_ANY(k + 4u < cnt)) break;
+    q0 = q1; q1 = q2; q2 = q3;
   }
 }
 
@@ -140,42 +211,83 @@ __host__ __device__ __forceinline__ void poly_for_each(const PolyRec &rec, const
 // among equal rooted distances; needed by the analytic gradient SHP:1505-1531) -- then the per-edge roots are taken
 // like the reference does; value only: min_i sqrt(d2_i) == sqrt(min_i d2_i) exactly (sqrt is correctly rounded and
 // monotone), one root per evaluation.  `edges` = pa.edges or a copy of it (LDS).
+//
+// Two paths with the same result.  The wave's path: both lists walked in step (poly_for_each), quotient from the edge's
+// reciprocal, crossing decided by the sign of a cross product, parity of a cell that is clear of the outline read from
+// its record.  The lane's own path, taken by the lanes the first one cannot serve -- a query outside both grids (all
+// edges), a list longer than kPolyInline, a projection outside poly_quot's range, a crossing angle within 1e-9 rad of 0
+// or pi: the lists (or all edges) walked by the lane with the division and the reference's atan2 formula.
 template <bool CLOSEST>
 __host__ __device__ inline double poly_sdf(const PolyAccel &pa, const PolyEdge *edges, double x, double y, double *cminx,
                                            double *cminy) {
-  double best = CLOSEST ? 1e9 : 1e300, mx = 0.0, my = 0.0;
-  auto visit = [&](int, const PolyEdge &e, double, double) {
-    double cx, cy;
-    const double d2 = poly_edge_d2(e, x, y, cx, cy);
-    if constexpr (CLOSEST) {
-      const double dis = sqrt(d2);
-      if (dis < best) { best = dis; mx = cx; my = cy; }
-    } else {
-      best = (d2 < best) ? d2 : best;
-    }
-  };
-  int cell = poly_cell(pa.lv[0], x, y);
-  unsigned base = pa.lv[0].base;
-  if (cell < 0) { cell = poly_cell(pa.lv[1], x, y); base = pa.lv[1].base; }
-  // the slab of the query's ray, when any edge can cross it
-  const bool ray = y >= pa.ymin - pa.tol && y <= pa.ymax + pa.tol && x <= pa.xmax + pa.tol;
+  unsigned base;
+  const int cell = poly_locate(pa, x, y, base);
+  // the slab and bucket of the query's ray, when any edge can cross it
+  const bool ray = (y >= pa.ymin - pa.tol) & (y <= pa.ymax + pa.tol) & (x <= pa.xmax + pa.tol);
   const double fs = (y - pa.ymin) * pa.slab_inv_h;
   const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
-  // both candidate records are fetched before either list is walked (two independent loads in flight instead of the
-  // second one waiting behind the distance loop)
+  const double fx = (x - pa.xmin) * pa.xb_inv_h;
+  const int xb = !(fx >= 0.0) ? 0 : (fx >= (double)pa.nxb) ? pa.nxb - 1 : (int)fx;
+  // one 32-byte record per query: the cell's distance candidates and what it knows about the crossing parity
   PolyRec rec_d, rec_p;
   for (int k = 0; k < 8; ++k) { rec_d.w[k] = 0u; rec_p.w[k] = 0u; }
   if (cell >= 0) rec_d = pa.cells[base + (unsigned)cell];
-  if (ray) rec_p = pa.slabs[slab];
-  if (cell >= 0) {
-    poly_for_each<false>(rec_d, pa.over, edges, pa.n, visit);
-  } else {
-    for (int i = 0; i < pa.n; ++i) visit(i, edges[i], 0.0, 0.0);
-  }
-  int rs = 0;
-  poly_for_each<true>(rec_p, pa.over, edges, pa.n, [&](int, const PolyEdge &e, double ex, double ey) {
-    if (poly_cross_ray(e.sx - x, e.sy - y, ex - x, ey - y)) rs++;   // end of edge i = start of the next edge
+  // parity: known for the whole cell (1 even, 2 odd), or the cell's own short list in the upper half of its record
+  // (3: words 4 .. 7, with the parity of the edges that cross every ray of the cell), or the slab's list (0)
+  const unsigned pstate = rec_d.w[7] >> 30;
+  const bool packed = pstate == 3u;
+  const bool walk = packed | (ray & (pstate == 0u));
+  if (ray & (pstate == 0u)) rec_p = pa.slabs[slab * pa.nxb + xb];   // rare: a dependent second fetch
+  const unsigned h15 = rec_d.w[7] >> 16;
+  const unsigned cnt_d = packed ? (h15 & 0xfu) : (h15 & kPolyCountMask);
+  const unsigned cnt_p = packed ? ((h15 >> 4) & 0xfu) : walk ? poly_count(rec_p) : 0u;
+  const int rs0 = (int)((pstate == 2u) | (packed & (((h15 >> 8) & 1u) != 0u)));
+  if (packed) { rec_p.w[0] = rec_d.w[4]; rec_p.w[1] = rec_d.w[5]; rec_p.w[2] = rec_d.w[6]; rec_p.w[3] = rec_d.w[7] & 0xffffu; }
+  bool own = (cell < 0) | (cnt_d > (unsigned)kPolyInline) | (cnt_p > (unsigned)kPolyInline) | (pa.div_ok == 0);
+
+  double best = CLOSEST ? 1e9 : 1e300, mx = 0.0, my = 0.0;
+  poly_for_each<false>(rec_d, own ? 0u : cnt_d, edges, pa.n, [&](bool valid, const PolyEdge &e, double, double) {
+    double cx, cy;
+    bool inrange;
+    const double d2 = poly_edge_d2<true>(e, x, y, cx, cy, inrange);
+    own = own | (valid & !inrange);
+    if constexpr (CLOSEST) {
+      const double dis = sqrt(d2);
+      const bool up = valid & (dis < best);
+      best = up ? dis : best; mx = up ? cx : mx; my = up ? cy : my;
+    } else {
+      best = (valid & (d2 < best)) ? d2 : best;
+    }
   });
+  int rs = rs0;
+  poly_for_each<true>(rec_p, own ? 0u : cnt_p, edges, pa.n, [&](bool valid, const PolyEdge &e, double ex, double ey) {
+    bool cross;   // end of edge i = start of the next edge
+    const bool sure = poly_cross_fast(e.sx - x, e.sy - y, ex - x, ey - y, cross);
+    rs += (valid & cross) ? 1 : 0;
+    own = own | (valid & !sure);
+  });
+  if (own) {
+    best = CLOSEST ? 1e9 : 1e300; mx = 0.0; my = 0.0;
+    const unsigned nd = (cell >= 0) ? cnt_d : (unsigned)pa.n;
+    for (unsigned k = 0; k < nd; ++k) {
+      const PolyEdge &e = edges[(cell >= 0) ? poly_list_index(rec_d, pa.over, cnt_d, k) : k];
+      double cx, cy;
+      bool inrange;
+      const double d2 = poly_edge_d2<false>(e, x, y, cx, cy, inrange);
+      if constexpr (CLOSEST) {
+        const double dis = sqrt(d2);
+        if (dis < best) { best = dis; mx = cx; my = cy; }
+      } else {
+        best = (d2 < best) ? d2 : best;
+      }
+    }
+    rs = rs0;
+    for (unsigned k = 0; k < cnt_p; ++k) {
+      const unsigned idx = poly_list_index(rec_p, pa.over, cnt_p, k);
+      const PolyEdge &e = edges[idx], &nx = edges[(idx + 1u == (unsigned)pa.n) ? 0u : idx + 1u];
+      if (poly_cross_ray(e.sx - x, e.sy - y, nx.sx - x, nx.sy - y)) rs++;
+    }
+  }
   double dis_min;
   if constexpr (CLOSEST) {
     dis_min = best;
@@ -196,7 +308,7 @@ struct PolyAccelHost {
   std::vector<unsigned short> over;
   PolyAccel hdr{};   // pointers unset
   // statistics
-  size_t cand_total = 0, cand_max = 0, slab_max = 0;
+  size_t cand_total = 0, cand_max = 0, slab_max = 0, par_total = 0, par_max = 0, cells_known = 0, cells_packed = 0, far_total = 0, far_max = 0;
 };
 
 namespace poly_detail {
@@ -237,15 +349,15 @@ inline double rect_seg_dist(const Seg &e, double x0, double y0, double x1, doubl
   return d;
 }
 // a candidate list (ascending edge indices) as a record; long lists go to `over`
-inline PolyRec pack_list(const std::vector<unsigned short> &list, std::vector<unsigned short> &over) {
+inline PolyRec pack_list(const std::vector<unsigned short> &list, std::vector<unsigned short> &over, unsigned pstate = 0) {
   unsigned short w[16] = {0};
-  w[0] = (unsigned short)list.size();
+  w[15] = (unsigned short)(list.size() | (pstate << 14));
   if (list.size() <= (size_t)kPolyInline) {
-    for (size_t k = 0; k < list.size(); ++k) w[1 + k] = list[k];
+    for (size_t k = 0; k < list.size(); ++k) w[k] = list[k];
   } else {
     const unsigned off = (unsigned)over.size();
-    w[1] = (unsigned short)(off & 0xffffu);
-    w[2] = (unsigned short)(off >> 16);
+    w[0] = (unsigned short)(off & 0xffffu);
+    w[1] = (unsigned short)(off >> 16);
     over.insert(over.end(), list.begin(), list.end());
   }
   PolyRec r;
@@ -256,13 +368,14 @@ inline PolyRec pack_list(const std::vector<unsigned short> &list, std::vector<un
 
 // returns false when the outline cannot be handled (n out of range, non-finite vertex)
 inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng_fine = 128, int ng_coarse = 256,
-                             int nslab = 256) {
+                             int nslab = 256, int refine = SVSDF_POLY_REFINE, int nxb = 32) {
   using namespace poly_detail;
   if (n < 3 || n > kPolyMaxVerts) return false;
   out = PolyAccelHost{};
   out.edges.resize(n);
   std::vector<Seg> seg(n);
   double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+  int div_ok = 1;
   for (int i = 0; i < n; ++i) {
     const int j = (i + 1 == n) ? 0 : i + 1;
     Seg &e = seg[i];
@@ -270,7 +383,8 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     if (!std::isfinite(e.sx) || !std::isfinite(e.sy)) return false;
     e.vx = e.ex - e.sx; e.vy = e.ey - e.sy;       // Eigen::Vector2d v = end - start
     e.vv = e.vx * e.vx + e.vy * e.vy;             // v.squaredNorm()
-    out.edges[i] = PolyEdge{e.sx, e.sy, e.vx, e.vy, e.vv};
+    out.edges[i] = PolyEdge{e.sx, e.sy, e.vx, e.vy, e.vv, (e.vv > 0.0) ? 1.0 / e.vv : 0.0};
+    if (e.vv > 0.0 && !(e.vv >= 1e-100 && e.vv <= 1e100)) div_ok = 0;
     xmin = std::min(xmin, e.sx); xmax = std::max(xmax, e.sx);
     ymin = std::min(ymin, e.sy); ymax = std::max(ymax, e.sy);
   }
@@ -278,13 +392,17 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
   const double scale = std::max(L, std::max(std::max(std::fabs(xmin), std::fabs(xmax)), std::max(std::fabs(ymin), std::fabs(ymax))));
   PolyAccel &h = out.hdr;
   h.n = n;
+  h.div_ok = div_ok;
   // ---- distance grids
   const double margins[2] = {0.25 * L, 3.0 * L};
   const int ngs[2] = {ng_fine, ng_coarse};
   const double grow = 1e-7 * scale;   // every cell is enlarged by this on all sides: a query whose cell index is decided
                                       // by the last bit of (x - x0) * inv_h is still covered by the neighbour's list
   std::vector<double> ub(n), row[2];
-  std::vector<unsigned short> list;
+  std::vector<unsigned short> list, plist;
+  std::vector<char> clear_of_outline;   // per cell: no edge within 1e-6 scale of it
+  std::vector<char> keep;
+  std::vector<double> dsub;
   for (int l = 0; l < 2; ++l) {
     PolyLevel &lv = h.lv[l];
     const double m = margins[l];
@@ -326,15 +444,133 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
         }
         const double thr = U * (1.0 + 1e-9) + 1e-9 * scale;
         list.clear();
+        double dcell = 1e300;   // distance of the enlarged cell to the outline
         for (int i = 0; i < n; ++i) {
           if (ub[i] - diam > thr) continue;   // cheap reject (1-Lipschitz): every point of the cell is farther than thr
-          if (rect_seg_dist(seg[i], cx0, cy0, cx1, cy1) <= thr) list.push_back((unsigned short)i);
+          const double dr = rect_seg_dist(seg[i], cx0, cy0, cx1, cy1);
+          if (dr <= thr) { list.push_back((unsigned short)i); dcell = std::min(dcell, dr); }
+        }
+        clear_of_outline.push_back(dcell > 1e-6 * scale ? 1 : 0);
+        // Second pass over the cell's own list, refine x refine sample points c, each standing for the sub-rectangle
+        // around it (half diagonal rho; the sub-rectangles tile the enlarged cell).  With e* the nearest listed edge at
+        // c, g(p) = d(p, e) - d(p, e*) has |grad g| = |u_e - u_e*| (unit vectors from the closest points a, b to p)
+        // <= 2 |a - b| / (d(p, e) + d(p, e*)) <= diam(e u e*) / (dmin(c) - rho) =: lip (and <= 2 always), so
+        // g(c) > lip * rho means e* is nearer than e in the whole sub-rectangle: e is the nearest edge nowhere in it.
+        // Kept = the union over the sub-rectangles of the edges that pass.  Far from a rounded corner all of its short
+        // edges are nearly equidistant (a bound on the distances alone keeps them all), but their bisectors fan out
+        // and lip is small there.
+        if (refine > 0 && list.size() > 1) {
+          const size_t m = list.size();
+          keep.assign(m, 0);
+          size_t nkept = 0;
+          const double sx = (cx1 - cx0) / refine, sy = (cy1 - cy0) / refine;
+          const double rho = 0.5 * std::sqrt(sx * sx + sy * sy) * (1.0 + 1e-9);
+          dsub.resize(m);
+          for (int jy = 0; jy < refine && nkept < m; ++jy)
+            for (int jx = 0; jx < refine && nkept < m; ++jx) {
+              const double px = cx0 + (jx + 0.5) * sx, py = cy0 + (jy + 0.5) * sy;
+              double dmin = 1e300;
+              size_t kmin = 0;
+              for (size_t k = 0; k < m; ++k) {
+                const Seg &e = seg[list[k]];
+                dsub[k] = (e.vv > 0.0) ? seg_point_dist(e, px, py) : 1e300;
+                if (dsub[k] < dmin) { dmin = dsub[k]; kmin = k; }
+              }
+              const Seg &b = seg[list[kmin]];
+              const double dlow = dmin * (1.0 - 1e-9) - rho - 1e-9 * scale;
+              for (size_t k = 0; k < m; ++k) {
+                if (keep[k]) continue;
+                double lip = 2.0;
+                if (dlow > 0.0) {
+                  const Seg &e = seg[list[k]];
+                  auto sq = [](double x, double y) { return x * x + y * y; };
+                  const double diam = std::sqrt(std::max(std::max(sq(e.sx - b.sx, e.sy - b.sy), sq(e.sx - b.ex, e.sy - b.ey)),
+                                                         std::max(sq(e.ex - b.sx, e.ey - b.sy), sq(e.ex - b.ex, e.ey - b.ey))));
+                  lip = std::min(2.0, diam * (1.0 + 1e-9) / dlow);
+                }
+                if (dsub[k] - dmin <= lip * rho * (1.0 + 1e-9) + 1e-9 * scale + 1e-9 * dsub[k]) { keep[k] = 1; ++nkept; }
+              }
+            }
+          if (nkept < m) {
+            size_t o = 0;
+            for (size_t k = 0; k < m; ++k) if (keep[k]) list[o++] = list[k];
+            list.resize(o);
+          }
         }
         out.cand_total += list.size();
         out.cand_max = std::max(out.cand_max, list.size());
         out.cells.push_back(pack_list(list, out.over));
+
       }
     }
+  }
+  // ---- far level: the candidate lists of a 256 x 256 grid out to 40 shape sizes, by descent through a pyramid of grids
+  // (16, 32, .. 256 cells per side).  A cell filters its parent's list with one sample, its centre c (half diagonal rho
+  // of the enlarged cell), by the bisector test of the second pass above: e* the nearest listed edge at c, e stays iff
+  // d(c, e) - d(c, e*) <= min(2, diam(e u e*) / (d(c, e*) - rho)) rho.  Every filter is valid for its whole cell, which
+  // contains the final cell.  (A query this far out used to walk all edges -- and with it the 63 other lanes of its wave:
+  // a tenth of the wave-level evaluations of config 5, 40 % of its vector instructions.)
+  {
+    PolyLevel &lv = h.lv[2];
+    const double ext = L + 2.0 * 40.0 * L;
+    const int ngf = 256;
+    lv.x0 = 0.5 * (xmin + xmax) - 0.5 * ext;
+    lv.y0 = 0.5 * (ymin + ymax) - 0.5 * ext;
+    lv.inv_h = 1.0 / (ext / ngf);
+    lv.nx = ngf; lv.ny = ngf;
+    lv.base = (unsigned)out.cells.size();
+    lv.pad = 0;
+    std::vector<std::vector<unsigned short>> cur(1), nxt;
+    for (int i = 0; i < n; ++i) if (seg[i].vv > 0.0) cur[0].push_back((unsigned short)i);
+    auto sq = [](double x, double y) { return x * x + y * y; };
+    for (int g = 1; g < ngf;) {
+      const int g2 = (g == 1) ? 16 : 2 * g, ratio = g2 / g;
+      const double hc = ext / g2;
+      nxt.assign((size_t)g2 * g2, {});
+      const double rho = 0.5 * std::sqrt(2.0) * (hc + 2.0 * grow) * (1.0 + 1e-9);
+      for (int iy = 0; iy < g2; ++iy)
+        for (int ix = 0; ix < g2; ++ix) {
+          const std::vector<unsigned short> &par = cur[(size_t)(iy / ratio) * g + ix / ratio];
+          std::vector<unsigned short> &dst = nxt[(size_t)iy * g2 + ix];
+          const double px = lv.x0 + (ix + 0.5) * hc, py = lv.y0 + (iy + 0.5) * hc;
+          const size_t m = par.size();
+          dsub.resize(m);
+          double dmin = 1e300;
+          size_t kmin = 0;
+          for (size_t k = 0; k < m; ++k) {
+            dsub[k] = seg_point_dist(seg[par[k]], px, py);
+            if (dsub[k] < dmin) { dmin = dsub[k]; kmin = k; }
+          }
+          if (m == 0) continue;
+          const Seg &b = seg[par[kmin]];
+          const double dlow = dmin * (1.0 - 1e-9) - rho - 1e-9 * scale;
+          for (size_t k = 0; k < m; ++k) {
+            double lip = 2.0;
+            if (dlow > 0.0) {
+              const Seg &e = seg[par[k]];
+              const double diam = std::sqrt(std::max(std::max(sq(e.sx - b.sx, e.sy - b.sy), sq(e.sx - b.ex, e.sy - b.ey)),
+                                                     std::max(sq(e.ex - b.sx, e.ey - b.sy), sq(e.ex - b.ex, e.ey - b.ey))));
+              lip = std::min(2.0, diam * (1.0 + 1e-9) / dlow);
+            }
+            if (dsub[k] - dmin <= lip * rho * (1.0 + 1e-9) + 1e-9 * scale + 1e-9 * dsub[k]) dst.push_back(par[k]);
+          }
+        }
+      cur.swap(nxt);
+      g = g2;
+    }
+    const double M = 1e-6 * scale + grow;
+    for (int iy = 0; iy < ngf; ++iy)
+      for (int ix = 0; ix < ngf; ++ix) {
+        const std::vector<unsigned short> &l2 = cur[(size_t)iy * ngf + ix];
+        const double hc = ext / ngf;
+        const double cx0 = lv.x0 + ix * hc, cx1 = cx0 + hc, cy0 = lv.y0 + iy * hc, cy1 = cy0 + hc;
+        // outside the outline's bounding box (by a margin): no ray of the cell meets it, or every edge is to its left
+        const bool outside = cx0 > xmax + M || cx1 < xmin - M || cy0 > ymax + M || cy1 < ymin - M;
+        out.far_total += l2.size();
+        out.far_max = std::max(out.far_max, l2.size());
+        out.cells.push_back(pack_list(l2, out.over, outside ? 1u : 0u));
+        clear_of_outline.push_back(0);   // (state set here)
+      }
   }
   // ---- parity slabs
   h.nslab = std::max(1, nslab);
@@ -342,6 +578,10 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
   h.tol = 1e-7 * scale;
   const double hs = std::max(ymax - ymin, 1e-300) / h.nslab;
   h.slab_inv_h = 1.0 / hs;
+  h.nxb = std::max(1, nxb);
+  h.xmin = xmin;
+  const double hx = std::max(xmax - xmin, 1e-300) / h.nxb;
+  h.xb_inv_h = 1.0 / hx;
   for (int s = 0; s < h.nslab; ++s) {
     // queries mapped to slab s have y in [ymin + s hs, ymin + (s + 1) hs] up to rounding of the index (the first and
     // last slab also take the queries within tol outside the y-range); listed: edges within 2 tol of that interval
@@ -352,7 +592,72 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
       if (std::max(e.sy, e.ey) >= a && std::min(e.sy, e.ey) <= b) list.push_back((unsigned short)i);
     }
     out.slab_max = std::max(out.slab_max, list.size());
-    out.slabs.push_back(pack_list(list, out.over));
+    // ... split by x: bucket b takes the queries with x >= xmin + b hx (bucket 0 also those left of xmin; up to the
+    // rounding of the index), whose ray to +x cannot meet an edge that lies entirely to the left of xmin + b hx by more
+    // than 2 tol -- both angles of such an edge are in (PI/2, 3 PI/2) with a margin of ~1e-8 rad, |theta_s - theta_e| < PI
+    for (int xb = 0; xb < h.nxb; ++xb) {
+      const double x0 = (xb == 0) ? -1e300 : xmin + xb * hx - 3.0 * h.tol;
+      plist.clear();
+      for (unsigned short i : list)
+        if (std::max(seg[i].sx, seg[i].ex) >= x0) plist.push_back(i);
+      out.par_total += plist.size();
+      out.par_max = std::max(out.par_max, plist.size());
+      out.slabs.push_back(pack_list(plist, out.over));
+    }
+  }
+  // ---- parity state of the grid cells.  A cell that stays clear of the outline by 1e-6 scale lies on one side of it,
+  // and for its queries the reference's crossing count has that parity: an edge's test |theta_s - theta_e| >= PI can only
+  // go either way under rounding when the query sees the edge under an angle within ~1e-15 of PI, i.e. lies within
+  // ~1e-15 scale of the segment; everywhere else the test is the half-open rule (end point on the ray line = above),
+  // applied with the same end-point values by both edges of a vertex.  The state is the count at the cell's centre.
+  for (int l = 0; l < 2; ++l) {
+    const PolyLevel &lv = h.lv[l];
+    const double hcell = 1.0 / lv.inv_h;
+    for (int iy = 0; iy < lv.ny; ++iy)
+      for (int ix = 0; ix < lv.nx; ++ix) {
+        const size_t c = (size_t)lv.base + (size_t)iy * lv.nx + ix;
+        if (!clear_of_outline[c]) {
+          // The outline passes (or may pass) through the cell: its own crossing list, when it fits the upper half of
+          // the record next to a distance list of <= 8 edges.  An edge entirely outside the cell's band of y (by 2 tol)
+          // or entirely to its left crosses no ray of the cell; one entirely to its right (by 1e-6 scale) whose end
+          // points lie on opposite sides of the band (by 1e-6 scale) crosses every ray of it -- an angle of at least
+          // ~1e-7 rad away from pi: those only flip the cell's base parity; the rest (an end point in the band, or
+          // overlapping the cell in x) are the list.
+          PolyRec &r = out.cells[c];
+          const unsigned cd = (r.w[7] >> 16) & kPolyCountMask;
+          if (cd > 8u) continue;
+          const double cx0 = lv.x0 + ix * hcell - grow, cx1 = lv.x0 + (ix + 1) * hcell + grow;
+          const double cy0 = lv.y0 + iy * hcell - grow - 2.0 * h.tol, cy1 = lv.y0 + (iy + 1) * hcell + grow + 2.0 * h.tol;
+          const double M = 1e-6 * scale;
+          unsigned basebit = 0;
+          plist.clear();
+          for (int i = 0; i < n; ++i) {
+            const Seg &e = seg[i];
+            const double ylo = std::min(e.sy, e.ey), yhi = std::max(e.sy, e.ey);
+            if (yhi < cy0 || ylo > cy1) continue;
+            if (std::max(e.sx, e.ex) < cx0 - 2.0 * h.tol) continue;
+            if (std::min(e.sx, e.ex) > cx1 + M && ylo < cy0 - M && yhi > cy1 + M) { basebit ^= 1u; continue; }
+            plist.push_back((unsigned short)i);
+          }
+          if (plist.size() > 7) continue;
+          for (size_t k = 0; k < plist.size(); ++k) {
+            const unsigned hw = 8u + (unsigned)k;   // halfword of the record
+            r.w[hw >> 1] = (hw & 1u) ? ((r.w[hw >> 1] & 0x0000ffffu) | ((unsigned)plist[k] << 16))
+                                     : ((r.w[hw >> 1] & 0xffff0000u) | (unsigned)plist[k]);
+          }
+          r.w[7] = (r.w[7] & 0x0000ffffu) | ((cd | ((unsigned)plist.size() << 4) | (basebit << 8) | (3u << 14)) << 16);
+          out.cells_packed++;
+          continue;
+        }
+        const double x = lv.x0 + (ix + 0.5) * hcell, y = lv.y0 + (iy + 0.5) * hcell;
+        int rs = 0;
+        if (y >= ymin && y <= ymax && x <= xmax)
+          for (int i = 0; i < n; ++i)
+            if (std::max(seg[i].sy, seg[i].ey) >= y && std::min(seg[i].sy, seg[i].ey) <= y &&
+                poly_cross_ray(seg[i].sx - x, seg[i].sy - y, seg[i].ex - x, seg[i].ey - y)) rs++;
+        out.cells[c].w[7] |= (rs % 2 == 0 ? 1u : 2u) << 30;
+        out.cells_known++;
+      }
   }
   return true;
 }

@@ -25,7 +25,7 @@ enum ShapeId : int {
   kPolygonLds = kShapeCount,
   kKernelShapeCount
 };
-constexpr int kPolyLdsMaxVerts = 1024;   // 40 KB of LDS
+constexpr int kPolyLdsMaxVerts = 1024;   // 48 KB of LDS
 
 // every kernel's `extern __shared__` array aliases the start of the block's dynamic LDS
 extern __shared__ double svsdf_dyn_lds[];
@@ -33,7 +33,7 @@ template <int SHAPE>
 constexpr bool is_polygon() { return SHAPE == kPolygon || SHAPE == kPolygonLds; }
 // doubles at the start of the dynamic LDS that hold the Polygon's edges (kPolygonLds kernels), else 0
 template <int SHAPE>
-__device__ __forceinline__ size_t poly_lds_doubles(int nverts) { return SHAPE == kPolygonLds ? 5 * (size_t)nverts : 0; }
+__device__ __forceinline__ size_t poly_lds_doubles(int nverts) { return SHAPE == kPolygonLds ? (size_t)kPolyEdgeDoubles * (size_t)nverts : 0; }
 
 // Host-prepared constants.  The reference evaluates cos/sin member initialisers with the host
 // libm at construction (SHP:855, 1237, 1278, 1320); we do the same on the host and pass them in.

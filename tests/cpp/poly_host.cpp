@@ -8,14 +8,19 @@
 
 using namespace svsdf;
 
+static int g_refine = SVSDF_POLY_REFINE;
+
 extern "C" {
+
+// second-pass resolution of the candidate lists for the calls below (1 = first pass only)
+void polyhost_set_refine(int r) { g_refine = r; }
 
 // stats_out[0..5]: fine-grid cells, coarse-grid cells, candidates (all cells), largest candidate list, entries in
 // long lists, largest slab list
 int polyhost_eval(const double *xy, int n, const double *pts, size_t P, double *sdf_out, double *sdfc_out,
                   double *closest_out, long long *stats_out) {
   PolyAccelHost h;
-  if (!build_poly_accel(xy, n, h)) return 1;
+  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
   PolyAccel pa = h.hdr;
   pa.edges = h.edges.data();
   pa.cells = h.cells.data();
@@ -37,18 +42,54 @@ int polyhost_eval(const double *xy, int n, const double *pts, size_t P, double *
   return 0;
 }
 
-// which list a query uses: 0 fine grid, 1 coarse grid, 2 full loop; and how many edges it visits
+// which list a query uses: 0 fine grid, 1 coarse grid, 2 far grid, 3 full loop; and how many edges it visits
 int polyhost_visits(const double *xy, int n, const double *pts, size_t P, int *level_out, int *count_out) {
   PolyAccelHost h;
-  if (!build_poly_accel(xy, n, h)) return 1;
+  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
   for (size_t i = 0; i < P; ++i) {
-    int cell = poly_cell(h.hdr.lv[0], pts[2 * i], pts[2 * i + 1]), lvl = 0;
-    if (cell < 0) { cell = poly_cell(h.hdr.lv[1], pts[2 * i], pts[2 * i + 1]); lvl = 1; }
-    if (cell < 0) { level_out[i] = 2; count_out[i] = n; continue; }
+    unsigned base = 0;
+    const int cell = poly_locate(h.hdr, pts[2 * i], pts[2 * i + 1], base);
+    if (cell < 0) { level_out[i] = 3; count_out[i] = n; continue; }
+    const int lvl = (base == h.hdr.lv[0].base) ? 0 : (base == h.hdr.lv[1].base) ? 1 : 2;
     level_out[i] = lvl;
-    count_out[i] = (int)(h.cells[h.hdr.lv[lvl].base + cell].w[0] & 0xffffu);
+    { const unsigned w7 = h.cells[h.hdr.lv[lvl].base + cell].w[7]; count_out[i] = (int)((w7 >> 30) == 3u ? ((w7 >> 16) & 0xfu) : ((w7 >> 16) & kPolyCountMask)); }
   }
   return 0;
+}
+
+// how many edges the crossing-parity loop of a query visits (0 when no edge can cross its ray)
+int polyhost_parity_visits(const double *xy, int n, const double *pts, size_t P, int *count_out) {
+  PolyAccelHost h;
+  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
+  const PolyAccel &pa = h.hdr;
+  for (size_t i = 0; i < P; ++i) {
+    const double x = pts[2 * i], y = pts[2 * i + 1];
+    unsigned base = 0;
+    const int cell = poly_locate(pa, x, y, base);
+    const bool ray = y >= pa.ymin - pa.tol && y <= pa.ymax + pa.tol && x <= pa.xmax + pa.tol;
+    const double fs = (y - pa.ymin) * pa.slab_inv_h;
+    const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
+    const double fx = (x - pa.xmin) * pa.xb_inv_h;
+    const int xb = !(fx >= 0.0) ? 0 : (fx >= (double)pa.nxb) ? pa.nxb - 1 : (int)fx;
+    count_out[2 * i] = ray ? (int)((h.slabs[slab * pa.nxb].w[7] >> 16) & kPolyCountMask) : 0;   // the whole slab
+    const unsigned w7 = (cell >= 0) ? h.cells[base + cell].w[7] : 0u;
+    const unsigned pstate = w7 >> 30;
+    count_out[2 * i + 1] = (pstate == 3u) ? (int)((w7 >> 20) & 0xfu)
+                         : (ray && pstate == 0u) ? (int)((h.slabs[slab * pa.nxb + xb].w[7] >> 16) & kPolyCountMask) : 0;   // as evaluated
+  }
+  return 0;
+}
+
+// poly_quot (through the same range test as poly_sdf) vs the division: q_out = what dis2Seg's t is computed from,
+// used_out = 1 where the refinement (not the division) produced it
+void polyhost_quot(const double *a, const double *b, size_t m, double *q_out, int *used_out) {
+  for (size_t i = 0; i < m; ++i) {
+    bool inrange;
+    const double q = poly_quot(a[i], b[i], (b[i] > 0.0) ? 1.0 / b[i] : 0.0, inrange);
+    const bool ok = inrange && b[i] >= 1e-100 && b[i] <= 1e100;   // PolyAccel::div_ok
+    q_out[i] = ok ? q : a[i] / b[i];
+    used_out[i] = ok ? 1 : 0;
+  }
 }
 
 }  // extern "C"
