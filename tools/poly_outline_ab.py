@@ -31,7 +31,7 @@ for _ in range(steps):
 ms = 1e3 * (time.perf_counter() - t0) / steps
 q = c.query_points(w["coeffs"], w["T"])
 h = hashlib.sha256()
-for a in (np.float64(out[0]), out[1], out[2], q):
+for a in (np.array([out[0]]), out[1], out[2], q[0], q[1], q[2]):
     h.update(np.ascontiguousarray(a).tobytes())
 print(json.dumps(dict(mesh=mesh, verts=len(w["polygon"]), ms=round(ms, 3), create_ms=round(create_ms, 1), hash=h.hexdigest()[:16])))
 '''
