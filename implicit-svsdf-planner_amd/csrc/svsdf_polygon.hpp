@@ -75,11 +75,16 @@ struct PolyAccel {
   double xmin, xb_inv_h;         // x buckets of the parity lists: [xmin, xmax] in nxb buckets (left of xmin: bucket 0)
   int nxb;
   int div_ok;                    // every edge's vv in [1e-100, 1e100]: poly_quot may refine instead of dividing
+  // the three levels as poly_locate reads them: common centre, half extent (shrunk by 1e-9), 1 / cell size, first record
+  double cx, cy, lr[3], linv[3];
+  unsigned lbase[3];
+  int pad2;
 };
 
 #ifndef SVSDF_POLY_REFINE
 #define SVSDF_POLY_REFINE 2   // sample points per cell side in the second pass of the candidate lists (0 = off)
 #endif
+constexpr int kPolyGrid = 256;        // cells per side of every grid level (poly_locate)
 constexpr int kPolyMaxVerts = 4096;   // = SVSDF_MAX_POLY_VERTS (16-bit edge indices; host build time)
 
 // true when the condition holds in any lane of the wave (the host build has one lane)
@@ -88,6 +93,21 @@ constexpr int kPolyMaxVerts = 4096;   // = SVSDF_MAX_POLY_VERTS (16-bit edge ind
 #else
 #define SVSDF_WAVE_ANY(c) (c)
 #endif
+// a wave-uniform value, as a scalar register (readfirstlane of a value the compiler already knows to be uniform folds away)
+__host__ __device__ __forceinline__ unsigned poly_uniform(unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+#else
+  return v;
+#endif
+}
+__host__ __device__ __forceinline__ double poly_uniform(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+#else
+  return v;
+#endif
+}
 
 // isCrossRayOnXDir (SHP:1370-1383): theta = atan2 wrapped to [0, 2pi), crossing iff |theta_s - theta_e| >= pi.
 // atan2(y, x) lies in (0, pi) for y > 0 and wraps into (pi, 2pi) for y < 0, so with both y != 0 the test is:
@@ -145,20 +165,25 @@ __host__ __device__ __forceinline__ double poly_edge_d2(const PolyEdge &e, doubl
   return dx * dx + dy * dy;
 }
 
-// the cell of (x, y) in level lv, or -1 when outside
-__host__ __device__ __forceinline__ int poly_cell(const PolyLevel &lv, double x, double y) {
-  const double fx = (x - lv.x0) * lv.inv_h, fy = (y - lv.y0) * lv.inv_h;
-  if (!(fx >= 0.0 && fy >= 0.0 && fx < (double)lv.nx && fy < (double)lv.ny)) return -1;   // also rejects NaN
-  return (int)fy * lv.nx + (int)fx;
-}
-
-// the innermost grid level that holds (x, y): its cell and the level's first record; -1 outside all three
+// the innermost grid level that holds (x, y): its cell and the level's first record; -1 outside all three.  The levels
+// share their centre, so the max-norm distance to it picks the level and ONE index computation follows (any level that
+// contains the query would do: each level's lists are complete on their own).  The host lays the cells out as
+// x0 + ix h; the two ways of computing an index differ by rounding only, which the cells' enlargement (`grow`) covers.
 __host__ __device__ __forceinline__ int poly_locate(const PolyAccel &pa, double x, double y, unsigned &base) {
-  int cell = poly_cell(pa.lv[0], x, y);
-  base = pa.lv[0].base;
-  if (cell < 0) { cell = poly_cell(pa.lv[1], x, y); base = pa.lv[1].base; }
-  if (cell < 0) { cell = poly_cell(pa.lv[2], x, y); base = pa.lv[2].base; }
-  return cell;
+  const double dx = x - pa.cx, dy = y - pa.cy;
+  const double ax = fabs(dx), ay = fabs(dy);
+  const double m = (ax > ay) ? ax : ay;
+  const bool l0 = m < pa.lr[0], l1 = m < pa.lr[1];
+  // (the header's values are pinned in scalar registers first: left to itself the compiler selects an ADDRESS per lane
+  // and loads the value from the header in memory, dependent loads in front of the record's)
+  const double i0 = poly_uniform(pa.linv[0]), i1 = poly_uniform(pa.linv[1]), i2 = poly_uniform(pa.linv[2]);
+  const unsigned b0 = poly_uniform(pa.lbase[0]), b1 = poly_uniform(pa.lbase[1]), b2 = poly_uniform(pa.lbase[2]);
+  const double inv = l0 ? i0 : l1 ? i1 : i2;
+  base = l0 ? b0 : l1 ? b1 : b2;
+  const double hn = 0.5 * kPolyGrid;
+  const double fx = dx * inv + hn, fy = dy * inv + hn, n = hn + hn;
+  if (!((fx >= 0.0) & (fy >= 0.0) & (fx < n) & (fy < n))) return -1;   // also rejects NaN and anything beyond the far level
+  return (int)fy * kPolyGrid + (int)fx;
 }
 
 __host__ __device__ __forceinline__ unsigned poly_count(const PolyRec &rec) { return (rec.w[7] >> 16) & kPolyCountMask; }
@@ -222,27 +247,30 @@ __host__ __device__ inline double poly_sdf(const PolyAccel &pa, const PolyEdge *
                                            double *cminy) {
   unsigned base;
   const int cell = poly_locate(pa, x, y, base);
-  // the slab and bucket of the query's ray, when any edge can cross it
-  const bool ray = (y >= pa.ymin - pa.tol) & (y <= pa.ymax + pa.tol) & (x <= pa.xmax + pa.tol);
-  const double fs = (y - pa.ymin) * pa.slab_inv_h;
-  const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
-  const double fx = (x - pa.xmin) * pa.xb_inv_h;
-  const int xb = !(fx >= 0.0) ? 0 : (fx >= (double)pa.nxb) ? pa.nxb - 1 : (int)fx;
   // one 32-byte record per query: the cell's distance candidates and what it knows about the crossing parity
-  PolyRec rec_d, rec_p;
-  for (int k = 0; k < 8; ++k) { rec_d.w[k] = 0u; rec_p.w[k] = 0u; }
-  if (cell >= 0) rec_d = pa.cells[base + (unsigned)cell];
-  // parity: known for the whole cell (1 even, 2 odd), or the cell's own short list in the upper half of its record
-  // (3: words 4 .. 7, with the parity of the edges that cross every ray of the cell), or the slab's list (0)
-  const unsigned pstate = rec_d.w[7] >> 30;
+  // (1 even / 2 odd for the whole cell; 3: the cell's own short list in words 4 .. 7 of the record, with the parity of the
+  // edges that cross every ray of the cell; 0: the list of the ray's slab and bucket -- a dependent second fetch, rare)
+  const PolyRec rec_d = pa.cells[base + (unsigned)((cell >= 0) ? cell : 0)];
+  const unsigned h15 = (cell >= 0) ? (rec_d.w[7] >> 16) : 0u;
+  const unsigned pstate = h15 >> 14;
   const bool packed = pstate == 3u;
-  const bool walk = packed | (ray & (pstate == 0u));
-  if (ray & (pstate == 0u)) rec_p = pa.slabs[slab * pa.nxb + xb];   // rare: a dependent second fetch
-  const unsigned h15 = rec_d.w[7] >> 16;
+  PolyRec rec_p;
+  rec_p.w[0] = rec_d.w[4]; rec_p.w[1] = rec_d.w[5]; rec_p.w[2] = rec_d.w[6]; rec_p.w[3] = rec_d.w[7] & 0xffffu;
+  rec_p.w[4] = 0u; rec_p.w[5] = 0u; rec_p.w[6] = 0u; rec_p.w[7] = 0u;
+  unsigned cnt_p = packed ? ((h15 >> 4) & 0xfu) : 0u;
+  if (SVSDF_WAVE_ANY(pstate == 0u)) {
+    const bool ray = (y >= pa.ymin - pa.tol) & (y <= pa.ymax + pa.tol) & (x <= pa.xmax + pa.tol);
+    if (ray & (pstate == 0u)) {
+      const double fs = (y - pa.ymin) * pa.slab_inv_h;
+      const int slab = !(fs >= 0.0) ? 0 : (fs >= (double)pa.nslab) ? pa.nslab - 1 : (int)fs;
+      const double fx = (x - pa.xmin) * pa.xb_inv_h;
+      const int xb = !(fx >= 0.0) ? 0 : (fx >= (double)pa.nxb) ? pa.nxb - 1 : (int)fx;
+      rec_p = pa.slabs[slab * pa.nxb + xb];
+      cnt_p = poly_count(rec_p);
+    }
+  }
   const unsigned cnt_d = packed ? (h15 & 0xfu) : (h15 & kPolyCountMask);
-  const unsigned cnt_p = packed ? ((h15 >> 4) & 0xfu) : walk ? poly_count(rec_p) : 0u;
   const int rs0 = (int)((pstate == 2u) | (packed & (((h15 >> 8) & 1u) != 0u)));
-  if (packed) { rec_p.w[0] = rec_d.w[4]; rec_p.w[1] = rec_d.w[5]; rec_p.w[2] = rec_d.w[6]; rec_p.w[3] = rec_d.w[7] & 0xffffu; }
   bool own = (cell < 0) | (cnt_d > (unsigned)kPolyInline) | (cnt_p > (unsigned)kPolyInline) | (pa.div_ok == 0);
 
   double best = CLOSEST ? 1e9 : 1e300, mx = 0.0, my = 0.0;
@@ -407,10 +435,12 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     PolyLevel &lv = h.lv[l];
     const double m = margins[l];
     const double ext = L + 2.0 * m;
-    const int ng = std::max(1, ngs[l]);
-    const double hcell = ext / ng;
-    lv.x0 = 0.5 * (xmin + xmax) - 0.5 * ext;
-    lv.y0 = 0.5 * (ymin + ymax) - 0.5 * ext;
+    // every level is 256 x 256 records around the common centre (poly_locate: one index formula); the fine level
+    // only fills the central ngs[0] x ngs[0] block of it, the cells its extent covers -- the rest is never looked up
+    const int ng = kPolyGrid, nfill = std::min(kPolyGrid, std::max(2, ngs[l])), lo = (ng - nfill) / 2, hi = lo + nfill;
+    const double hcell = ext / nfill;
+    lv.x0 = 0.5 * (xmin + xmax) - 0.5 * ng * hcell;
+    lv.y0 = 0.5 * (ymin + ymax) - 0.5 * ng * hcell;
     lv.inv_h = 1.0 / hcell;
     lv.nx = ng; lv.ny = ng;
     lv.base = (unsigned)out.cells.size();
@@ -424,12 +454,22 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
         for (int i = 0; i < n; ++i) r[(size_t)ix * n + i] = seg_point_dist(seg[i], x, y);
       }
     };
-    fill_row(row[0], 0);
+    fill_row(row[lo & 1], lo);
     const double diam = 1.4143 * (hcell + 2.0 * grow);
     for (int iy = 0; iy < ng; ++iy) {
+      if (iy < lo || iy >= hi) {
+        out.cells.resize(out.cells.size() + ng, PolyRec{{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}});
+        clear_of_outline.resize(clear_of_outline.size() + ng, 2);   // 2: not a cell of this level
+        continue;
+      }
       fill_row(row[(iy + 1) & 1], iy + 1);
       const std::vector<double> &r0 = row[iy & 1], &r1 = row[(iy + 1) & 1];
       for (int ix = 0; ix < ng; ++ix) {
+        if (ix < lo || ix >= hi) {
+          out.cells.push_back(PolyRec{{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}});
+          clear_of_outline.push_back(2);
+          continue;
+        }
         const double cx0 = lv.x0 + ix * hcell - grow, cx1 = lv.x0 + (ix + 1) * hcell + grow;
         const double cy0 = lv.y0 + iy * hcell - grow, cy1 = lv.y0 + (iy + 1) * hcell + grow;
         // U >= the nearest-edge distance of every point of the enlarged cell: the distance to a segment is convex
@@ -616,6 +656,7 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     for (int iy = 0; iy < lv.ny; ++iy)
       for (int ix = 0; ix < lv.nx; ++ix) {
         const size_t c = (size_t)lv.base + (size_t)iy * lv.nx + ix;
+        if (clear_of_outline[c] == 2) continue;
         if (!clear_of_outline[c]) {
           // The outline passes (or may pass) through the cell: its own crossing list, when it fits the upper half of
           // the record next to a distance list of <= 8 edges.  An edge entirely outside the cell's band of y (by 2 tol)
@@ -659,6 +700,17 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
         out.cells_known++;
       }
   }
+  h.cx = 0.5 * (xmin + xmax); h.cy = 0.5 * (ymin + ymax);
+  for (int l = 0; l < 3; ++l) {
+    const PolyLevel &lv = h.lv[l];
+    if (lv.nx != kPolyGrid || lv.ny != kPolyGrid) return false;
+    h.linv[l] = lv.inv_h;
+    h.lbase[l] = lv.base;
+  }
+  h.lr[0] = 0.5 * (L + 2.0 * margins[0]) * (1.0 - 1e-9);
+  h.lr[1] = 0.5 * (L + 2.0 * margins[1]) * (1.0 - 1e-9);
+  h.lr[2] = 0.5 * (L + 2.0 * 40.0 * L) * (1.0 - 1e-9);
+  h.pad2 = 0;
   return true;
 }
 }  // namespace svsdf
