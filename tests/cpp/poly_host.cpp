@@ -92,4 +92,24 @@ void polyhost_quot(const double *a, const double *b, size_t m, double *q_out, in
   }
 }
 
+// the grid cell poly_locate gives a query, as the rectangle the host built that cell's lists for (before its enlargement):
+// rect_out[4 i ..] = x0, y0, x1, y1 (NaN when the query is outside all levels); level_out: 0 fine, 1 coarse, 2 far, 3 none
+int polyhost_cell_rect(const double *xy, int n, const double *pts, size_t P, double *rect_out, int *level_out) {
+  PolyAccelHost h;
+  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
+  for (size_t i = 0; i < P; ++i) {
+    unsigned base = 0;
+    const int cell = poly_locate(h.hdr, pts[2 * i], pts[2 * i + 1], base);
+    if (cell < 0) { level_out[i] = 3; for (int k = 0; k < 4; ++k) rect_out[4 * i + k] = std::nan(""); continue; }
+    const int l = (base == h.hdr.lv[0].base) ? 0 : (base == h.hdr.lv[1].base) ? 1 : 2;
+    const PolyLevel &lv = h.hdr.lv[l];
+    const int ix = cell % lv.nx, iy = cell / lv.nx;
+    const double hc = 1.0 / lv.inv_h;
+    level_out[i] = l;
+    rect_out[4 * i] = lv.x0 + ix * hc; rect_out[4 * i + 1] = lv.y0 + iy * hc;
+    rect_out[4 * i + 2] = lv.x0 + (ix + 1) * hc; rect_out[4 * i + 3] = lv.y0 + (iy + 1) * hc;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -327,3 +327,57 @@ def test_poly_quot_is_the_division(polyhost):
         ref = a / b
     assert (q.view(np.int64) == ref.view(np.int64)).all()
     assert used.mean() > 0.99 and not used[:8].any()                       # the refinement served all but the odd ones
+
+
+def test_cell_lookup_agrees_with_the_cells_the_lists_were_built_for(polyhost):
+    """poly_locate computes a cell index from the distance to the levels' common centre; the host lays the cells out
+    from each level's corner.  The two may differ by rounding only: every query must lie within 1e-9 sizes of the
+    rectangle of the cell it is given (the lists hold for the rectangle enlarged by 1e-7 sizes), on grid lines too."""
+    from svsdf_amd import workload
+    rng = np.random.default_rng(21)
+    for name in ("star", "sdHeart", "sdArc"):
+        xy = np.ascontiguousarray(workload.mesh_outline(name) + np.array([37.25, -11.5]))   # off-centre on purpose
+        n = len(xy)
+        size = max(np.ptp(xy[:, 0]), np.ptp(xy[:, 1]))
+        c = 0.5 * (xy.min(0) + xy.max(0))
+        ext = np.array([1.5, 7.0, 81.0]) * size
+        pts = [c + rng.uniform(-0.5 * e, 0.5 * e, (20000, 2)) for e in ext]
+        for e in ext:                                    # on and next to the grid lines of every level
+            k = rng.integers(-128, 129, (20000, 2))
+            q = c + k * (e / (128 if e == ext[0] else 256)) * (1.0 if e != ext[0] else 1.0)
+            pts += [q, np.nextafter(q, np.inf), np.nextafter(q, -np.inf)]
+        pts = np.ascontiguousarray(np.concatenate(pts))
+        rect = np.zeros((len(pts), 4))
+        lv = np.zeros(len(pts), dtype=np.int32)
+        assert polyhost.polyhost_cell_rect(_dp(xy), n, _dp(pts), C.c_size_t(len(pts)), _dp(rect),
+                                           lv.ctypes.data_as(C.POINTER(C.c_int))) == 0
+        inside = lv < 3
+        assert inside.mean() > 0.9 and {0, 1, 2} <= set(lv.tolist())
+        tol = 1e-9 * size
+        p, r = pts[inside], rect[inside]
+        assert (p[:, 0] >= r[:, 0] - tol).all() and (p[:, 0] <= r[:, 2] + tol).all()
+        assert (p[:, 1] >= r[:, 1] - tol).all() and (p[:, 1] <= r[:, 3] + tol).all()
+        # the innermost level that holds the query is used (a query well inside the fine extent gets a fine cell)
+        m = np.max(np.abs(pts - c), axis=1)
+        assert (lv[m < 0.74 * size] == 0).all() and (lv[(m > 0.76 * size) & (m < 3.49 * size)] == 1).all()
+        assert (lv[(m > 3.51 * size) & (m < 40.4 * size)] == 2).all() and (lv[m > 40.6 * size] == 3).all()
+
+
+def test_polygon_outlines_outside_the_quotient_range(polyhost):
+    """Outlines so small / large that v.v leaves [1e-100, 1e100]: PolyAccel::div_ok is off and every lane evaluates on its
+    own path (the division itself); and an outline far from the origin.  Bit-identical to the oracle's plain loop."""
+    from svsdf_amd import workload
+    rng = np.random.default_rng(33)
+    base = np.ascontiguousarray(workload.mesh_outline("star"))
+    for scale, shift in ((1e-60, 0.0), (1e60, 0.0), (1.0, 1e6), (1e-3, -250.0)):
+        xy = np.ascontiguousarray(base * scale + shift)
+        size = max(np.ptp(xy[:, 0]), np.ptp(xy[:, 1]))
+        c = 0.5 * (xy.min(0) + xy.max(0))
+        pts = np.ascontiguousarray(np.concatenate([c + rng.uniform(-0.7 * size, 0.7 * size, (8000, 2)),
+                                                   c + rng.uniform(-6 * size, 6 * size, (4000, 2)),
+                                                   c + rng.uniform(-60 * size, 60 * size, (2000, 2)), xy]))
+        so, go = orc.Oracle("Polygon", polygon=xy).shape_eval(pts, grad=True)
+        s, sc, cl = np.zeros(len(pts)), np.zeros(len(pts)), np.zeros((len(pts), 2))
+        assert polyhost.polyhost_eval(_dp(xy), len(xy), _dp(pts), C.c_size_t(len(pts)), _dp(s), _dp(sc), _dp(cl), None) == 0
+        assert (s.view(np.int64) == so.view(np.int64)).all(), (scale, shift)
+        assert (sc.view(np.int64) == so.view(np.int64)).all(), (scale, shift)
