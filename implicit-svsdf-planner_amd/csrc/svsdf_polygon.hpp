@@ -50,14 +50,17 @@ constexpr int kPolyEdgeDoubles = 6;
 
 // A candidate list in one 32-byte record of 16-bit words h[0 .. 15]: h[15] = count | parity state << 14; count <= 15:
 // h[0 .. count - 1] = the edges, ascending; count > 15: h[0] | h[1] << 16 = offset of the list in `over`.  One 32-byte
-// load gives a query its whole list in registers (no dependent load per edge).  Parity state (distance records of grid
-// cells only): 0 = run the crossing test, 1 = every query of the cell is outside (even crossings), 2 = inside.
+// load gives a query its whole list in registers (no dependent load per edge).  Parity state (records of grid cells
+// only): 0 = take the crossing list of the ray's slab and bucket, 1 = every query of the cell is outside (even
+// crossings), 2 = inside, 3 = the cell's own crossing list is in the same record: h[15] = distance count (4 bits) |
+// crossing count << 4 (4 bits) | parity of the edges that cross every ray of the cell << 8 | 3 << 14, distance edges in
+// h[0 .. 7], crossing edges in h[8 .. 14].
 struct alignas(32) PolyRec { unsigned w[8]; };
 constexpr int kPolyInline = 15;
 constexpr unsigned kPolyCountMask = 0x1fffu;   // counts up to kPolyMaxVerts = 4096
 
 struct PolyLevel {
-  double x0, y0, inv_h;   // cell (ix, iy) = floor((x - x0) * inv_h), floor((y - y0) * inv_h)
+  double x0, y0, inv_h;   // cell (ix, iy) = [x0 + ix h, x0 + (ix + 1) h] x [y0 + iy h, ..], h = 1 / inv_h (host layout; poly_locate)
   int nx, ny;
   unsigned base;          // first record of this level in `cells` (nx * ny records)
   int pad;
@@ -67,7 +70,7 @@ struct PolyAccel {
   int n;                         // edges = vertices
   int nslab;
   const PolyEdge *edges;
-  const PolyRec *cells;          // candidate edges per grid cell (both levels) + the cell's parity state
+  const PolyRec *cells;          // candidate edges per grid cell (three levels) + what the cell knows about the crossing parity
   const PolyRec *slabs;          // crossing-parity candidates per (slab of y, bucket of x): nslab * nxb records
   const unsigned short *over;    // lists longer than kPolyInline
   PolyLevel lv[3];               // 0 fine (around the outline), 1 coarse (to 3 shape sizes), 2 far (to 40 shape sizes)
