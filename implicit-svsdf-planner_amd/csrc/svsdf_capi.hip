@@ -182,6 +182,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n > 0) ctx->n_cu = n;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && n > 0) ctx->lds_limit = (size_t)n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeWallClockRate, ctx->device) == hipSuccess && n > 0) ctx->wall_clock_khz = (double)n;
   }
   if (const char *e = std::getenv("SVSDF_CULL")) { ctx->cull = std::atoi(e) != 0; ctx->cull2 = std::atoi(e) >= 2; }   // 0 none, 1 circle bound only, 2 both (default)
   if (const char *e = std::getenv("SVSDF_TAIL")) ctx->tail_mode = (std::string(e) == "off") ? -2 : (std::string(e) == "auto") ? -1 : std::max(0, std::atoi(e));
@@ -517,6 +518,24 @@ int svsdf_group_info(const svsdf_ctx *ctx, int *n_devices, int *combine, int *rc
   if (rccl_ranks) {
     *rccl_ranks = rccl_comm_count(ctx);   // asked of the communicator itself (ncclCommCount); 0: none
   }
+  return SVSDF_OK;
+}
+
+int svsdf_group_stripe(const svsdf_ctx *ctx, int k, int *device, size_t *points, svsdf_stats *stats, svsdf_plan *plan) {
+  if (!ctx) return SVSDF_ERR_INVALID;
+  const int G = ctx->subs.empty() ? 1 : (int)ctx->subs.size();
+  if (k < 0 || k >= G) return SVSDF_ERR_INVALID;
+  const svsdf_ctx *s = ctx->subs.empty() ? ctx : ctx->subs[k];
+  if (device) *device = s->device;
+  if (points) *points = s->P;
+  if (stats) *stats = s->stats;
+  if (plan) return svsdf_get_plan(s, plan);
+  return SVSDF_OK;
+}
+
+int svsdf_set_group_serial(svsdf_ctx *ctx, int serial) {
+  if (!ctx || ctx->subs.empty()) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_set_group_serial: not a multi-device context");
+  ctx->group_serial = serial != 0;
   return SVSDF_OK;
 }
 

@@ -116,6 +116,7 @@ struct svsdf_ctx {
   bool block_env = false;      // env SVSDF_BLOCK pins the solve kernel's block size (default: by LDS footprint)
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 3, delta_all_iter = 5;
   int n_cu = 256;
+  double wall_clock_khz = 100000.0;   // hipDeviceAttributeWallClockRate: rate of the constant counter of the clock probe
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)
   bool ub_lazy = false;        // with ub_full: only the samples in the cheap-bound band are scanned (k_round MODE 2)
@@ -194,7 +195,8 @@ struct svsdf_ctx {
   double *h_red = nullptr;          // pinned: reduced partial read back from subs[0]
   std::vector<double> comb;         // host-combined [cost | gradC | gradT]
   const double *h_partial = nullptr;  // where the last evaluation's summed partial lives on the host
-  double combine_ms = 0.0, setup_ms = 0.0;
+  double combine_ms = 0.0, setup_ms = 0.0, fanout_ms = 0.0;
+  bool group_serial = false;        // svsdf_set_group_serial: the stripes' evaluations one after the other (diagnostic)
 
   // svsdf_swept_outline: the last result, so that the documented query-then-fill protocol runs the extraction once
   std::vector<double> ol_key, ol_xy;
@@ -214,7 +216,7 @@ struct svsdf_ctx {
 namespace svsdf_impl {
 
 constexpr size_t kOutPartial = 19 * svsdf::kMaxPieces + 1;
-constexpr size_t kOutDoubles = kOutPartial + 12 + 2 * svsdf::kMaxIter;   // partial | 9 counters | solves per iteration | round scans | speculative | active per iteration | interior found
+constexpr size_t kOutDoubles = kOutPartial + 14 + 2 * svsdf::kMaxIter;   // partial | 9 counters | solves per iteration | round scans | speculative | active per iteration | interior found | clock probe (2)
 constexpr int kRepeat = -12345;   // finish(): more interior points than capacity -- the arrays were grown, repeat the evaluation
 
 extern thread_local std::string g_last_error;

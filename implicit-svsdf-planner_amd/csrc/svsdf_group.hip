@@ -40,16 +40,40 @@ int upload_group_device(svsdf_ctx *ctx, const double *d_xyz, size_t P) {
 // run f(k) for every sub-context on its worker thread; first non-zero return code wins
 int group_run(svsdf_ctx *ctx, const std::function<int(int)> &f) {
   const int G = (int)ctx->subs.size();
-  for (int k = 0; k < G; ++k) ctx->workers[k]->post([&f, k] { return f(k); });
+  using clk = std::chrono::steady_clock;
+  std::vector<clk::time_point> ts(G), te(G);
+  auto job = [&f, &ts, &te](int k) { ts[k] = clk::now(); const int r = f(k); te[k] = clk::now(); return r; };
   int rc = SVSDF_OK;
-  for (int k = 0; k < G; ++k) {
-    const int r = ctx->workers[k]->wait();
+  auto collect = [&](int k, int r) {
     if (r && !rc) {
       rc = r;
       ctx->err = "device " + std::to_string(ctx->subs[k]->device) + " (stripe " + std::to_string(k) + "): " + ctx->subs[k]->err;
       g_last_error = ctx->err;
     }
+  };
+  double wake = 0.0, join = 0.0;
+  auto ms = [](clk::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
+  if (ctx->group_serial) {
+    // diagnostic (svsdf_set_group_serial): the stripes one after the other, so that on a box with fewer GPUs than stripes
+    // every stripe's device time is its own -- what it would take on a GPU of its own
+    for (int k = 0; k < G; ++k) {
+      const clk::time_point t_post = clk::now();
+      ctx->workers[k]->post([&job, k] { return job(k); });
+      collect(k, ctx->workers[k]->wait());
+      wake += ms(ts[k] - t_post);
+      join += ms(clk::now() - te[k]);
+    }
+  } else {
+    const clk::time_point t_post = clk::now();
+    for (int k = 0; k < G; ++k) ctx->workers[k]->post([&job, k] { return job(k); });
+    for (int k = 0; k < G; ++k) collect(k, ctx->workers[k]->wait());
+    const clk::time_point t_done = clk::now();
+    clk::time_point last_start = ts[0], last_end = te[0];
+    for (int k = 1; k < G; ++k) { last_start = std::max(last_start, ts[k]); last_end = std::max(last_end, te[k]); }
+    wake = ms(last_start - t_post);
+    join = ms(t_done - last_end);
   }
+  ctx->fanout_ms = wake + join;
   return rc;
 }
 
@@ -124,6 +148,9 @@ void merge_stats(svsdf_ctx *ctx) {
     t.gsip_bound_mode = std::max(t.gsip_bound_mode, a.gsip_bound_mode);
     t.piece_time_exact = std::max(t.piece_time_exact, a.piece_time_exact);
     t.bound_ratio = std::max(t.bound_ratio, a.bound_ratio);
+    if (a.shader_clock_mhz > 0.0) t.shader_clock_mhz = (t.shader_clock_mhz > 0.0) ? std::min(t.shader_clock_mhz, a.shader_clock_mhz) : a.shader_clock_mhz;
+    t.small_ms = std::max(t.small_ms, a.small_ms);
+    t.small_path = std::max(t.small_path, a.small_path);
   }
   t.bound_mode_decided = 1;
   t.plan_settled = 1;
@@ -131,6 +158,7 @@ void merge_stats(svsdf_ctx *ctx) {
   t.n_devices = (int)ctx->subs.size();
   t.combine = ctx->combine;
   t.combine_ms = ctx->combine_ms;
+  t.fanout_ms = ctx->fanout_ms;
   t.setup_ms = ctx->setup_ms;
   ctx->stats = t;
 }
@@ -222,12 +250,23 @@ std::string group_init_rccl(svsdf_ctx *g) {
   }
   const int e = g_rccl.CommInitAll(g->comms.data(), G, devs.data());
   if (e) { g->comms.clear(); return std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); }
+  //  a failure from here on must not leave a half-initialised group behind: svsdf_set_combine's early-out above
+  // would take the populated `comms` for a ready communicator and run the all-reduce into null buffers
+  auto undo = [&](const char *m) -> std::string {
+    for (int k = 0; k < G; ++k)
+      if (g->comms[k] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comms[k]);
+    g->comms.clear();
+    for (size_t k = 0; k < g->d_red.size(); ++k)
+      if (g->d_red[k]) { (void)hipSetDevice(devs[k]); (void)hipFree(g->d_red[k]); }
+    g->d_red.clear();
+    return m;
+  };
   g->d_red.assign(G, nullptr);
   for (int k = 0; k < G; ++k)
     if (hipSetDevice(devs[k]) != hipSuccess || hipMalloc((void **)&g->d_red[k], kOutPartial * sizeof(double)) != hipSuccess)
-      return "allocation of the all-reduce buffer failed";
+      return undo("allocation of the all-reduce buffer failed");
   if (!g->h_red && hipHostMalloc((void **)&g->h_red, kOutPartial * sizeof(double), hipHostMallocDefault) != hipSuccess)
-    return "pinned allocation failed";
+    return undo("pinned allocation failed");
   return "";
 }
 

@@ -90,6 +90,10 @@ struct BatchCtl {
   // (tools/experiments/coh_latency.hip), a full grid of waves ending together would queue up behind four words of one
   // cache line -- the waves spread over kStatSlots lines, k_finish adds them up
   StatSlot stat[kStatSlots];
+  // clock probe (round 5): shader-clock cycles (s_memtime) and constant-rate cycles (s_memrealtime) block 0's first wave of
+  // this batch's MAIN solve spent between its table staging and its last query -- both counters read by the same wave, so
+  // their ratio is the shader clock the evaluation actually ran at (svsdf_stats.shader_clock_mhz), whatever rocm-smi says
+  unsigned long long clk[2];
 };
 
 // Piece durations for wave-uniform indices: the same T[] of the TrajDev in global memory, read through the constant
@@ -448,6 +452,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
     c.nonfinite = 0;
     c.n_int = 0;
+    c.clk[0] = 0ull; c.clk[1] = 0ull;
   }
   for (int i = threadIdx.x; i < nbatch * kStatSlots; i += blockDim.x) {
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
@@ -1133,6 +1138,8 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   const int li = Grp<G>::li();
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0, n_spec = 0;
   unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  const bool clk_probe = work_idx == 0 && blockIdx.x == 0 && threadIdx.x < 64;   // (wave-uniform; BatchCtl::clk)
+  const long long clk_c0 = clk_probe ? clock64() : 0ll, clk_r0 = clk_probe ? wall_clock64() : 0ll;
   // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
   // the launch's cursor.  (All waves of a launch start together: with a fetch first, their 3000 atomics on one address
   // take ~ 12 ns each, one after the other -- the last wave would start ~ 37 us late, in every launch of the chain.)
@@ -1181,6 +1188,10 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       out_t[slot] = x;
       ++n_solved;
     }
+  }
+  if (clk_probe && threadIdx.x == 0) {
+    ctl->clk[0] = (unsigned long long)(clock64() - clk_c0);
+    ctl->clk[1] = (unsigned long long)(wall_clock64() - clk_r0);
   }
   unsigned long long te = (unsigned long long)n_eval + n_scan, ts = n_solved, tc = n_scan, tu = n_culled, tp = n_spec;
 #pragma unroll
@@ -2360,6 +2371,8 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
     stats_out[9 + kMaxIter] = rs;
     stats_out[10 + kMaxIter] = sp_;
     stats_out[11 + 2 * kMaxIter] = (unsigned long long)ctl[0].n_int;   // interior points found (may exceed the capacity: repeat)
+    stats_out[12 + 2 * kMaxIter] = ctl[0].clk[0];                       // clock probe of batch 0's main solve (BatchCtl::clk)
+    stats_out[13 + 2 * kMaxIter] = ctl[0].clk[1];
     for (int i = 0; i < kMaxIter; ++i) {   // active GSIP points per iteration: the host places the fused tail (k_tail) by them
       unsigned long long na = 0;
       for (int b = 0; b < nbatch; ++b) na += (unsigned long long)ctl[b].n_active[i];

@@ -577,6 +577,10 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   ctx->stats.round_scan_evals = st[9 + kMaxIter];
   ctx->stats.speculative_evals = st[10 + kMaxIter];
   ctx->stats.batches = ctx->nbatch;
+  {
+    const unsigned long long c = st[12 + 2 * kMaxIter], r = st[13 + 2 * kMaxIter];   // clock probe (BatchCtl::clk)
+    ctx->stats.shader_clock_mhz = r ? (double)c / (double)r * ctx->wall_clock_khz * 1e-3 : 0.0;
+  }
   for (int i = 0; i < kMaxIter; ++i) ctx->prev_nsolve[i] = (long long)st[9 + i];
   ctx->have_prev_nsolve = true;
   for (int i = 0; i < kMaxIter; ++i) ctx->prev_nactive[i] = (long long)st[11 + kMaxIter + i];

@@ -30,6 +30,7 @@ EXPORTS = [
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
     "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline", "svsdf_outline_extrude",
     "svsdf_get_plan", "svsdf_set_plan", "svsdf_set_combine", "svsdf_group_info", "svsdf_debug_sdf_at",
+    "svsdf_group_stripe", "svsdf_set_group_serial",
 ]
 
 
@@ -68,7 +69,8 @@ class Stats(C.Structure):
                 ("round_ms", C.c_double), ("round_ms_sum", C.c_double), ("batches", C.c_int),
                 ("speculative_evals", C.c_ulonglong), ("plan_settled", C.c_int), ("tail_iter", C.c_int),
                 ("tail_launches", C.c_uint), ("tail_points", C.c_ulonglong), ("tail_ms", C.c_double),
-                ("tail_ms_sum", C.c_double)]
+                ("tail_ms_sum", C.c_double), ("shader_clock_mhz", C.c_double), ("fanout_ms", C.c_double),
+                ("small_ms", C.c_double), ("small_path", C.c_int)]
 
 
 class Plan(C.Structure):
@@ -173,6 +175,9 @@ def lib():
         L.svsdf_set_plan.argtypes = [C.c_void_p, C.POINTER(Plan)]
         L.svsdf_set_combine.argtypes = [C.c_void_p, C.c_int]
         L.svsdf_group_info.argtypes = [C.c_void_p, _ip, _ip, _ip]
+    if hasattr(L, "svsdf_group_stripe"):
+        L.svsdf_group_stripe.argtypes = [C.c_void_p, C.c_int, _ip, C.POINTER(C.c_size_t), C.POINTER(Stats), C.POINTER(Plan)]
+        L.svsdf_set_group_serial.argtypes = [C.c_void_p, C.c_int]
     _LIB = L
     return L
 
@@ -645,6 +650,17 @@ class SvsdfContext:
         nd, cb, rk = C.c_int(), C.c_int(), C.c_int()
         self._chk(self.L.svsdf_group_info(self.ctx, C.byref(nd), C.byref(cb), C.byref(rk)), "svsdf_group_info")
         return {"n_devices": nd.value, "combine": ["auto", "host", "rccl"][cb.value], "rccl_ranks": rk.value}
+
+    def group_stripe(self, k):
+        """Stripe k of a multi-device context (svsdf_group_stripe): device, points, its stats and plan."""
+        dev, pts, st, pl = C.c_int(), C.c_size_t(), Stats(), Plan()
+        self._chk(self.L.svsdf_group_stripe(self.ctx, int(k), C.byref(dev), C.byref(pts), C.byref(st), C.byref(pl)), "svsdf_group_stripe")
+        return {"device": dev.value, "points": pts.value, "stats": {n: getattr(st, n) for n, _ in Stats._fields_},
+                "plan": {n: getattr(pl, n) for n, _ in Plan._fields_}}
+
+    def set_group_serial(self, serial=True):
+        """Diagnostic: the stripes of a multi-device context one after the other (svsdf_set_group_serial)."""
+        self._chk(self.L.svsdf_set_group_serial(self.ctx, int(bool(serial))), "svsdf_set_group_serial")
 
     def set_profiling(self, enable=True):
         self._chk(self.L.svsdf_set_profiling(self.ctx, int(enable)), "svsdf_set_profiling")   # 2: serialised batches

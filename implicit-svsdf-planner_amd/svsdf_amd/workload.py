@@ -57,11 +57,8 @@ _ASSETS = None
 def reference_mesh(name):
     """(V (nv, 3), F (nf, 3) zero-based) of the reference's shapes/<name>.obj, from the committed data fixture
     (tests/golden/reference_assets.json, written by tests/golden/make_fixtures.py)."""
-    global _ASSETS
-    if _ASSETS is None:
-        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        _ASSETS = json.load(open(os.path.join(root, "tests", "golden", "reference_assets.json")))
-    return np.array(_ASSETS["shapes"][name], dtype=np.float64), np.array(_ASSETS["mesh_faces"][name], dtype=np.int32)
+    a = _assets()
+    return np.array(a["shapes"][name], dtype=np.float64), np.array(a["mesh_faces"][name], dtype=np.int32)
 
 
 def mesh_outline(name, z0=0.0):
@@ -168,6 +165,40 @@ def make(config="C2", P=None, N=None, dist="corridor", seed=SEED, minco=None):
     if minco is not None:
         w["coeffs"] = minco(hs, ts, q, T)
     return w
+
+
+def _assets():
+    global _ASSETS
+    if _ASSETS is None:
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        _ASSETS = json.load(open(os.path.join(root, "tests", "golden", "reference_assets.json")))
+    return _ASSETS
+
+
+def reference_case(name, N=24, iterates=8, seed=SEED):
+    """The regime the reference runs (plan_manager.cpp:156-175, back_end_optimizer.cpp:29-36): its own demo map
+    (src/plan_manager/pcds/map_<name>.pcd, 210 ... 380 points; data fixture) through the query-point producer (occupancy
+    grid -> AABB gather of half width kernel_size * resolution / 3 around the waypoints), N MINCO pieces from the demo's
+    start to its end pose, and `iterates` optimiser variables x = [tau, q] whose durations are GENERIC doubles (2.5 s *
+    (1 + 1e-3 N(0, 1)), waypoints moved by ~1 cm from one to the next) like the successive LMBM iterates of one
+    optimisation.  Needs the built library (host-side producer)."""
+    from . import binding
+    a = _assets()
+    sc = a["scenarios"][name]
+    cloud = np.array(a["maps"][name], dtype=np.float32)
+    q = waypoints(sc["start"][:2], sc["end"][:2], N)
+    halfbd = np.full(3, sc["kernel_size"] * sc["occupancy_resolution"] / 3.0)
+    pts = binding.OccupancyMap(cloud, sc["occupancy_resolution"], 1).gather(q, halfbd)
+    hs, ts = states(sc["start"][:2], sc["end"][:2])
+    rng = np.random.default_rng(seed)
+    xs = []
+    for _ in range(iterates):
+        T = sc["inittime"] * (1.0 + 1e-3 * rng.standard_normal(N))
+        qq = q + 1e-2 * rng.standard_normal(q.shape)
+        xs.append(x_from(qq, T, binding.backward_T))
+    return dict(name=name, shape=name, N=N, points=pts, map_points=len(cloud), xs=xs, q=q,
+                safety_hor=sc["safety_hor"], weight_p=sc["weight_p"], rho=sc["rho"], poly_params=sc["poly_params"],
+                threads_num=int(sc["threads_num"]), head_state=hs, tail_state=ts, polygon=None)
 
 
 def x_from(q, T, backward_T):

@@ -382,6 +382,16 @@ typedef struct svsdf_stats {
   unsigned long long tail_points;     /* GSIP points still active when the tail took over */
   double tail_ms;                     /* HIP-event time during which >= 1 k_tail launch was executing (profiling on) */
   double tail_ms_sum;                 /* plain sum of the k_tail launch durations (profiling on) */
+  double shader_clock_mhz;            /* shader clock the evaluation ran at, measured by the kernel itself: cycles of the
+                                         shader-clock counter (s_memtime) per cycle of the constant-rate counter (s_memrealtime,
+                                         hipDeviceAttributeWallClockRate) over the life of the first wave of the main solve; a
+                                         multi-device context reports its slowest device; 0 when nothing ran */
+  double fanout_ms;                   /* multi-device contexts: host wall time of the evaluation that is neither a device's
+                                         pipeline nor the combine -- waking the per-device threads (post -> the last thread
+                                         starts) + joining them (the last thread done -> the caller runs again) */
+  double small_ms;                    /* HIP-event time of the fused small-cloud kernel (k_small), when it ran (profiling on) */
+  int small_path;                     /* 1: the last evaluation ran as ONE launch (k_small: tables, main solve, GSIP loop and
+                                         reduction fused; clouds of a few thousand points), 0: the launch chain */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 
@@ -412,6 +422,14 @@ int svsdf_set_combine(svsdf_ctx *ctx, int combine);
 /* Devices driven by the context, combine mode in force, and the rank count of the RCCL communicator as reported by the
  * communicator itself (ncclCommCount; 0 when none exists).  Any out pointer may be NULL. */
 int svsdf_group_info(const svsdf_ctx *ctx, int *n_devices, int *combine, int *rccl_ranks);
+/* One stripe of a multi-device context (k < n_devices; a single-device context has the one stripe 0): the device it lives
+ * on, its point count, the counters / times of ITS part of the last evaluation and the launch plan it follows.  Any out
+ * pointer may be NULL.  What an 8-GPU run is judged by -- stripe balance (device_ms max / mean), the plan every stripe
+ * picked -- can so be read per stripe; with several stripes on one GPU (svsdf_config::devices repeating an ordinal)
+ * svsdf_set_group_serial(ctx, 1) makes every stripe's device_ms its own. */
+int svsdf_group_stripe(const svsdf_ctx *ctx, int k, int *device, size_t *points, svsdf_stats *stats, svsdf_plan *plan);
+/* Diagnostic: serial != 0 runs the stripes' evaluations one after the other instead of concurrently (same results). */
+int svsdf_set_group_serial(svsdf_ctx *ctx, int serial);
 /* Shape bound used by the exact scan pruning and the exact cull: out2[0] = R with sdf_shape(q) >= |q| - R
  * (analytic circumradius of the shape + |offset|, Shape.hpp:281-294 / :531-1476), out2[1] = the largest
  * |q| - sdf_shape(q) found on a polar grid out to 60 m at context creation (self-check: <= out2[0]). */
