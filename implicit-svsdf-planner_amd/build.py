@@ -21,9 +21,11 @@ DEPS = sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(HERE, "..", "i
 OUT = os.path.join(HERE, "libsvsdf_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 NSLICES = 4
-# what a slice object depends on (svsdf_shape_slice.hip's include closure); the api object depends on everything
-SLICE_DEPS = [os.path.join(CSRC, f) for f in ("svsdf_shape_slice.hip", "svsdf_launch.hpp", "svsdf_kernels.hpp",
-                                               "svsdf_shapes.hpp", "svsdf_polygon.hpp", "svsdf_frontend.hpp")]
+# what a slice object depends on: its own source and EVERY header of csrc/ (a hand-kept include closure went stale the
+# moment a kernel header gained an include -- stale slice objects would then link silently against a changed SolveLaunch /
+# GsipState layout); the host objects depend on everything
+SLICE_DEPS = [os.path.join(CSRC, "svsdf_shape_slice.hip")] + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + \
+             [os.path.join(HERE, "..", "include", "svsdf_c.h")]
 
 # -ffp-contract=off: the parity build rounds every operation like the reference's x86-64 build
 # (no FMA contraction); see DESIGN.md "Floating-point policy".
@@ -66,8 +68,12 @@ def build(force=False, verbose=False, out=OUT, extra_flags=(), tag=""):
                 all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps if os.path.exists(d))):
             objs_kept.append(obj)
             continue
-        open(stamp, "w").write(flags_key)
-        cmd = [hipcc] + CFLAGS + list(extra_flags) + defs + ["-c", src, "-o", obj]
+        # compile to a temporary name; object and flags stamp appear only after the compiler succeeded (an interrupted
+        # compile must not leave a truncated object that looks newer than its sources)
+        for stale in (stamp, obj + ".tmp"):
+            if os.path.exists(stale):
+                os.remove(stale)
+        cmd = [hipcc] + CFLAGS + list(extra_flags) + defs + ["-c", src, "-o", obj + ".tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, obj, subprocess.Popen(cmd, cwd=HERE)))
@@ -78,6 +84,8 @@ def build(force=False, verbose=False, out=OUT, extra_flags=(), tag=""):
                 if q.poll() is None:
                     q.kill()
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        os.replace(obj + ".tmp", obj)
+        open(obj + ".flags", "w").write(flags_key)
         objs.append(obj)
     link = [hipcc] + LDFLAGS + objs + ["-o", out]
     if verbose:

@@ -105,7 +105,13 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     return nullptr;
   };
   if (hipSetDevice(dev) != hipSuccess) return bail("hipSetDevice failed");
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  {
+    StreamSet ss;   // from the process-wide pool: created once per device, never destroyed (svsdf_ctx.hpp)
+    if (!acquire_streams(dev, ss)) return bail("hipStreamCreate failed");
+    ctx->stream = ss.main;
+    for (int b = 0; b < kMaxBatches; ++b) ctx->bstream[b] = ss.batch[b];
+    ctx->stream_slot = ss.slot;
+  }
   // shape constants, evaluated with the host libm exactly where the reference does (SHP:281-294,
   // :855, :1237, :1278, :1320)
   ShapeParams &sp = ctx->sp;
@@ -194,9 +200,8 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     else if (std::string(e) == "fast") ctx->cfg.flags |= SVSDF_FLAG_FAST_PIECE_TIME;
   }
   for (int b = 0; b < kMaxBatches; ++b) {
-    if (hipStreamCreateWithFlags(&ctx->bstream[b], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming) != hipSuccess)
-      return bail("stream/event creation failed");
+    if (hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming) != hipSuccess)
+      return bail("event creation failed");
   }
   if (hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess) return bail("event creation failed");
   if (hipMalloc((void **)&ctx->d_traj, sizeof(TrajDev)) != hipSuccess ||
@@ -213,15 +218,20 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
      // sample of |q| - sdf(q) (k_rbound, out to 60 m) is kept as a self-check of that bound, not as its source.
     const double r0 = shape_circumradius(cfg->shape_id, ctx->poly_xy.data(), sp.nverts);
     const double analytic = (r0 + std::hypot(sp.tx, sp.ty)) * (1.0 + 1e-12) + 1e-6;
-    if (hipMemsetAsync(ctx->d_out, 0, sizeof(double), ctx->stream) != hipSuccess) return bail("hipMemset failed");
+    if (hipMemsetAsync(ctx->d_out, 0, 2 * sizeof(double), ctx->stream) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;
     const unsigned grid = (unsigned)((nrad * nang + kBlock - 1) / kBlock);
     (void)launch_k_rbound(cfg->shape_id, grid, ctx->stream, ctx->sp, 60.0, nrad, nang, ctx->d_out);
-    double rb = 0.0;
-    if (hipMemcpyAsync(&rb, ctx->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+    double rbl[2] = {0.0, 0.0};
+    if (hipMemcpyAsync(rbl, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
       return bail("shape bound kernel failed");
+    const double rb = rbl[0];
     ctx->r_bound_sampled = rb;
+    // 1-Lipschitz self-check of the shape SDF (k_rbound): the value-based second cull and the anchor bound mode are exact
+    // only for such a function; a shape that fails (none of the 17 does) runs without both
+    ctx->lipschitz_excess = rbl[1];
+    if (rbl[1] > 0.0 || std::getenv("SVSDF_ASSUME_NOT_LIPSCHITZ")) { ctx->lipschitz_ok = false; ctx->cull2 = false; }
     if (rb > analytic)
       return bail("svsdf_create: sampled shape bound " + std::to_string(rb) + " exceeds the analytic circumradius " +
                   std::to_string(analytic) + " (internal error: the pruning bound would be unsafe)");
@@ -256,11 +266,15 @@ void svsdf_destroy(svsdf_ctx *ctx) {
   if (ctx->h_fe) (void)hipHostFree(ctx->h_fe);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
-  for (int b = 0; b < kMaxBatches; ++b) {
+  for (int b = 0; b < kMaxBatches; ++b)
     if (ctx->ev_done[b]) (void)hipEventDestroy(ctx->ev_done[b]);
-    if (ctx->bstream[b]) (void)hipStreamDestroy(ctx->bstream[b]);
+  if (ctx->stream_slot >= 0) {   // the streams go back to the pool (idle: the device was synchronised above)
+    StreamSet ss;
+    ss.main = ctx->stream;
+    for (int b = 0; b < kMaxBatches; ++b) ss.batch[b] = ctx->bstream[b];
+    ss.slot = ctx->stream_slot;
+    release_streams(ctx->device, ss);
   }
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -447,6 +461,15 @@ int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]) {
   const svsdf_ctx *c = ctx->subs.empty() ? ctx : ctx->subs[0];
   out2[0] = c->r_bound;
   out2[1] = c->r_bound_sampled;
+  return SVSDF_OK;
+}
+
+int svsdf_shape_selfcheck(const svsdf_ctx *ctx, double out3[3]) {
+  if (!ctx || !out3) return SVSDF_ERR_INVALID;
+  const svsdf_ctx *c = ctx->subs.empty() ? ctx : ctx->subs[0];
+  out3[0] = c->r_bound;
+  out3[1] = c->r_bound_sampled;
+  out3[2] = c->lipschitz_ok ? 0.0 : std::max(c->lipschitz_excess, 1e-300);
   return SVSDF_OK;
 }
 

@@ -78,6 +78,7 @@ struct svsdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;               // main stream: upload, prep, assemble, readback
   hipStream_t bstream[svsdf::kMaxBatches] = {};      // one stream per point batch
+  int stream_slot = -1;                       // which set of the process-wide stream pool these are (acquire_streams)
   hipEvent_t ev_prep = nullptr, ev_done[svsdf::kMaxBatches] = {};
   svsdf::ShapeParams sp{};
   bool poly_lds = false;             // Polygon: k_solve / k_round run their kPolygonLds variants (edges at the start of LDS)
@@ -104,6 +105,8 @@ struct svsdf_ctx {
   size_t pose_cap = 0;
   double r_bound = 0.0;    // shape bound radius for the layer-1 chunk pruning (analytic circumradius + offset)
   double r_bound_sampled = 0.0;  // max over a polar grid of |q| - sdf(q): self-check, must not exceed r_bound
+  double lipschitz_excess = 0.0; // largest |f(q') - f(q)| - |q' - q| found by the same grid (k_rbound); must be <= 0
+  bool lipschitz_ok = true;      // false: the shape SDF is not 1-Lipschitz -> no value-based cull, no anchor bound mode
   double traj_duration = 0.0;
   bool have_duration = false;
   bool host_only = false;  // SVSDF_FLAG_HOST_ONLY: MINCO / callback host logic only, no device
@@ -242,13 +245,23 @@ int dev_alloc(svsdf_ctx *ctx, T **p, size_t count) {
 // throughput (narrow groups waste fewer lanes; the descent's ladders share the wave anyway).  Crossovers re-measured in
 // round 4 after the shared ladders (profiles/r04_lanes_sweep.txt: 100 k points 8 -> 4 lanes - 5 %, 200 k 8 -> 2 lanes - 7 %).
 // (Polygon: never below 4 -- its 2-lane kernel spills under the 3-waves register cap.)
-inline int bound_mode_of(const svsdf_ctx *c) { return c->ub_full ? (c->ub_lazy ? 2 : (c->ub_anchor ? 3 : 1)) : 0; }
+inline int bound_mode_of(const svsdf_ctx *c) { return c->ub_full ? (c->ub_lazy ? 2 : ((c->ub_anchor && c->lipschitz_ok) ? 3 : 1)) : 0; }
 inline int default_lanes(const svsdf_ctx *ctx, size_t Ps) {
   const int g = (Ps < 3000) ? 32 : (Ps < 20000) ? 16 : (Ps < 75000) ? 8 : (Ps < 150000) ? 4 : 2;
   return (ctx->cfg.shape_id == (int)svsdf::kPolygon) ? std::max(g, 4) : g;
 }
 
 // ---- svsdf_pipeline.hip
+// Streams come from a process-wide pool and go back to it (round 5).  A context used to create its 9 streams and destroy
+// them with itself; the NEXT context of the process then ran its concurrent point batches 7 % slower -- same kernels, same
+// plan, same serialised times (tools/state_probe.py: a workload after any destroyed context 7.6 - 7.7 ms, beside a live
+// one or in a fresh process 7.1 ms): the runtime maps streams to hardware queues when they are created and tears the
+// queues down with the last stream, so the second generation of streams overlaps differently.  Pooled streams are created
+// once per device in a fixed order and never destroyed: every context that is alone on its device gets set 0, i.e. the
+// stream-to-queue mapping of a fresh process.
+struct StreamSet { hipStream_t main = nullptr; hipStream_t batch[svsdf::kMaxBatches] = {}; int slot = -1; };
+bool acquire_streams(int device, StreamSet &out);
+void release_streams(int device, StreamSet &s);
 int set_batches(svsdf_ctx *ctx, int nb);
 int choose_tail_iter(const svsdf_ctx *ctx);
 int swept_field(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, double *sdf_sorted);

@@ -501,21 +501,34 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
 
 // Shape bound radius: max over a polar grid of |q| - sdf_shape(q) (body frame, including the
 // shape's own offset/rotation).  For an exact SDF this is the circumradius about the origin.
+// out[1] (round 5): 1-Lipschitz self-check of the shape SDF -- the second exact cull (scan_layer1) and the
+// anchor bound mode (k_round MODE 3) rest on |f(a) - f(b)| <= |a - b|, which holds for every exact distance function but is
+// asserted nowhere else: the largest excess |f(q') - f(q)| - |q' - q| (1 + 1e-9) - 1e-12 over the grid samples q and four
+// neighbours q' each (1 mm steps in x and y: the scale of the cull's allowances; the radial and angular grid neighbours:
+// ~ 0.1 m).  A positive value switches both devices off for the context (svsdf_create).
 template <int SHAPE>
 __global__ void k_rbound(ShapeParams sp, double rmax, int nrad, int nang, double *__restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  double v = -1e300;
+  double v = -1e300, lip = -1e300;
   if (idx < nrad * nang) {
     const int ir = idx / nang, ia = idx % nang;
     const double r = rmax * (double)(ir + 1) / (double)nrad;
     const double a = 2.0 * kPI * (double)ia / (double)nang;
     const double x = r * cos(a), y = r * sin(a);
-    v = r - shape_sdf<SHAPE>(sp, x, y);
+    const double f0 = shape_sdf<SHAPE>(sp, x, y);
+    v = r - f0;
+    auto excess = [&](double xx, double yy) {
+      const double d = norm2(xx - x, yy - y);
+      return fabs(shape_sdf<SHAPE>(sp, xx, yy) - f0) - d * (1.0 + 1e-9) - 1e-12;
+    };
+    const double r2 = rmax * (double)(ir + 2) / (double)nrad, a2 = 2.0 * kPI * (double)(ia + 1) / (double)nang;
+    lip = fmax(fmax(excess(x + 1e-3, y), excess(x, y + 1e-3)), fmax(excess(r2 * cos(a), r2 * sin(a)), excess(r * cos(a2), r * sin(a2))));
   }
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+  for (int m = 32; m >= 1; m >>= 1) { v = fmax(v, __shfl_xor(v, m, 64)); lip = fmax(lip, __shfl_xor(lip, m, 64)); }
   if ((threadIdx.x & 63) == 0) {
     // atomic max on a non-negative double via its integer ordering
     if (v > 0.0) atomicMax((unsigned long long *)out, (unsigned long long)__double_as_longlong(v));
+    if (lip > 0.0) atomicMax((unsigned long long *)(out + 1), (unsigned long long)__double_as_longlong(lip));
   }
 }
 
@@ -783,16 +796,19 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
       c = c + first + 1;
     }
     if (!culled) finish_scan();
-    // Second exact cull (round 4; main points, shapes whose SDF is an exact distance function, i.e. 1-Lipschitz: all 17).
-    // The first one knows a chunk only by its bounding circle (|p - c| - rb: loose by up to the shape's circumradius --
-    // 15 % of C3's points are inactive yet survive it).  After the scan the table VALUES are known: for a time t of an
-    // EVALUATED chunk's interval, within h of a table time t_k,  q(t) = R(t)^T (p - x(t))  moves by at most
-    // h (V_c + W_c |p - x|)  (V_c, W_c: Bernstein bounds of planar speed and yaw rate on the interval, host), so
-    // sdf(t) >= sdf(t_k) - h (V_c + W_c (|p - c| + rb_c));  a PRUNED chunk has every table value above the running
-    // minimum and, by the circle argument,  sdf(t) >= lb_c - slack_c > best_d - max_c slack_c.  If the smaller of the two
-    // bounds exceeds safety_hor, every pose of the continuous path keeps the point inactive whatever local minimum the
-    // reference's search returns: it contributes exactly zero and the 215 evaluations of layers 2-4 and the descent
-    // are skipped.
+    // Second exact cull (round 4; main points; needs a 1-Lipschitz shape SDF: true of every exact distance function, i.e.
+    // all 17 shapes, and self-checked per context by k_rbound -- a shape that fails runs without it).
+    // The first cull knows a chunk only by its bounding circle (|p - c| - rb: loose by up to the shape's circumradius --
+    // 15 % of C3's points are inactive yet survive it).  After the scan the table VALUES are known.  For a time t of an
+    // EVALUATED chunk's interval, within h of a table time t_k, the body-frame point q(t) = R(t)^T (p - x(t)) obeys
+    //   q(t) - q(t_k) = R(t)^T (x_k - x(t)) + (R(t) - R(t_k))^T (p - x_k),
+    // so |q(t) - q(t_k)| <= h V_c + h W_c |p - x_k|  (V_c, W_c: Bernstein bounds of planar speed and yaw rate on the
+    // interval, host; |R(t) - R(t_k)| <= |yaw(t) - yaw(t_k)|), and |p - x_k| <= |p - c| + r_c <= |p - c| + rb_c (x_k lies in
+    // the chunk's circle).  By the Lipschitz property  sdf(t) >= sdf(t_k) - h (V_c + W_c (|p - c| + rb_c)).  A PRUNED chunk
+    // has every table value above the running minimum and, by the circle argument,  sdf(t) >= lb_c - slack_c > best_d -
+    // max_c slack_c.  If the smaller of the two bounds exceeds safety_hor, every pose of the continuous path keeps the
+    // point inactive whatever local minimum the reference's search returns: it contributes exactly zero and the 215
+    // evaluations of layers 2-4 and the descent are skipped.
     if (!culled && rot) {
       const double bound = dmin(vbound, best_d - slack_max) - 1e-9;
       if (bound > cull_thresh) { culled = true; best_d = bound; best_k = 0; }
@@ -2043,12 +2059,13 @@ template <int SHAPE, int G>
 __device__ __forceinline__ void tail_solve_pass(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
                                                 const Pose *pose, const Chunk *chunks, int K, int nch, const GsipState &gs,
                                                 const unsigned *qlist, int base, int nq, int prune, void *wave_lds,
-                                                unsigned &n_eval, unsigned &n_scan, unsigned &n_solved, unsigned &n_spec) {
+                                                unsigned &n_eval, unsigned &n_scan, unsigned &n_solved, unsigned &n_spec,
+                                                unsigned long long (&sc)[12]) {
   const int lane = (int)(threadIdx.x & 63);
   const int li = Grp<G>::li();
   const int q = base + lane / G;
   const bool live = q < nq;
-  unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  const unsigned long long t_scan0 = SVSDF_SITE_CLOCK();
   size_t slot = 0;
   double px = 0.0, py = 0.0;
   double best_d = 1e9;
@@ -2065,6 +2082,7 @@ __device__ __forceinline__ void tail_solve_pass(const TrajL &tr, const double *_
                             culled, n_scan, nullptr, -1, nullptr);
     }
   }
+  SVSDF_SITE_CYCLES(sc, 8, t_scan0);
   double x = 0.0, fx = 0.0;
   descend_from_seed<SHAPE, G, 1>(tr, tk, sp, px, py, live, best_k, best_d, x, fx, n_eval, n_spec, sc, wave_lds);   // whole wave
   if (live && li == 0) {
@@ -2113,6 +2131,8 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   const unsigned lt_mask = (1u << l) - 1u;
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_spec = 0, n_rscan = 0;
   unsigned long long rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_wave0 = SVSDF_SITE_CLOCK();
   int n_emit_tot = 0;
   // work: the wave's first two points are its own (wave index: no atomic), further ones come kTailFetch at a time
   // ppw = points per wave: 2 (one per half-wave), or 1 when the launch holds few points -- a pure latency chain then, and
@@ -2172,12 +2192,12 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (nq > 0) {
       if (nq <= 2) {
-        tail_solve_pass<SHAPE, 32>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
+        tail_solve_pass<SHAPE, 32>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
       } else if (nq <= 8) {
-        tail_solve_pass<SHAPE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
+        tail_solve_pass<SHAPE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
       } else {
         for (int base = 0; base < nq; base += 32)
-          tail_solve_pass<SHAPE, 2>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, base, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec);
+          tail_solve_pass<SHAPE, 2>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, base, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -2201,6 +2221,21 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     if (em) atomicAdd(&ctl->n_seed[it0], em);
     if (ts) atomicAdd(&ctl->n_solve[it0], (int)ts);
   }
+#ifdef SVSDF_SITE_STATS
+  if (lane == 0) {   // wave cycles per phase: round_point's (pad[12 ..], like k_round) and the solve passes' (pad[8 .. 10], like k_solve)
+    rc[6] = SVSDF_SITE_CLOCK() - t_wave0;
+    StatSlot *ss = stat_slot(ctl->stat);
+    for (int i = 0; i < 8; ++i) if (rc[i]) atomicAdd(&ss->pad[12 + i], rc[i]);
+    for (int i = 8; i < 11; ++i) if (sc[i]) atomicAdd(&ss->pad[i], sc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {   // site executions (0 .. 3) and evaluating lanes (4 .. 7), like k_solve
+    unsigned long long v = sc[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0 && v) atomicAdd(&stat_slot(ctl->stat)->pad[i], v);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,6 +33,42 @@ inline uint32_t part1by1(uint32_t x) {
   return x;
 }
 
+// process-wide stream pool (svsdf_ctx.hpp): per device, sets of 1 + kMaxBatches non-blocking streams
+namespace {
+struct PoolEntry { StreamSet set; bool in_use = false; };
+std::mutex g_pool_mutex;
+std::vector<std::vector<PoolEntry>> g_pool;   // [device][slot]
+}  // namespace
+
+bool acquire_streams(int device, StreamSet &out) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  if (device < 0) return false;
+  if ((size_t)device >= g_pool.size()) g_pool.resize((size_t)device + 1);
+  std::vector<PoolEntry> &pool = g_pool[(size_t)device];
+  for (size_t k = 0; k < pool.size(); ++k)
+    if (!pool[k].in_use) { pool[k].in_use = true; out = pool[k].set; return true; }   // lowest free slot first
+  PoolEntry e;
+  e.set.slot = (int)pool.size();
+  bool ok = hipStreamCreateWithFlags(&e.set.main, hipStreamNonBlocking) == hipSuccess;
+  for (int b = 0; b < kMaxBatches && ok; ++b) ok = hipStreamCreateWithFlags(&e.set.batch[b], hipStreamNonBlocking) == hipSuccess;
+  if (!ok) {
+    if (e.set.main) (void)hipStreamDestroy(e.set.main);
+    for (int b = 0; b < kMaxBatches; ++b) if (e.set.batch[b]) (void)hipStreamDestroy(e.set.batch[b]);
+    return false;
+  }
+  e.in_use = true;
+  pool.push_back(e);
+  out = e.set;
+  return true;
+}
+
+void release_streams(int device, StreamSet &s) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  if (device >= 0 && (size_t)device < g_pool.size() && s.slot >= 0 && (size_t)s.slot < g_pool[(size_t)device].size())
+    g_pool[(size_t)device][(size_t)s.slot].in_use = false;
+  s = StreamSet{};
+}
+
 size_t next_event(svsdf_ctx *ctx) {
   if (ctx->ev_used == ctx->ev_pool.size()) {
     hipEvent_t e = nullptr;
@@ -750,7 +786,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     const bool large = ctx->P >= 400000;
     ctx->ub_full = ctx->ub_ratio > thr || large;
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
-    if (ctx->ub_full && !ctx->ub_lazy) ctx->an_state = 1;   // full scans pay: does the anchor variant pay more?
+    if (ctx->ub_full && !ctx->ub_lazy && ctx->lipschitz_ok) ctx->an_state = 1;   // full scans pay: does the anchor variant pay more?
     if (ctx->ub_full) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }   // the launch plan on record is the cheap-bound one
   }
   // the batch count follows once the bound mode is known (also when it was pinned)
@@ -1059,6 +1095,8 @@ int upload_shard_device(svsdf_ctx *ctx, const double *d_xyz, size_t P, int rk, i
 // svsdf_debug_sdf_at: upload the trajectory (same path as an evaluation: k_prep, piece-time mode), evaluate on the device
 int debug_sdf_at(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, size_t n, const double *pxy, const double *t,
                  double *out8) {
+  if (n == 0) return SVSDF_OK;
+  if (n > 0x7fffffffull) return fail(ctx, SVSDF_ERR_INVALID, "svsdf_debug_sdf_at: too many queries");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->ev_used = 0;
   const size_t e0 = next_event(ctx);
@@ -1078,7 +1116,8 @@ int debug_sdf_at(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, s
       cleanup();
       return fail(ctx, SVSDF_ERR_INVALID, "svsdf_debug_sdf_at: shape not compiled into this build");
     }
-    e = hipMemcpyAsync(out8, d_o, 8 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    e = hipGetLastError();   // a failed launch is this function's error, not the next evaluation's
+    if (e == hipSuccess) e = hipMemcpyAsync(out8, d_o, 8 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   cleanup();

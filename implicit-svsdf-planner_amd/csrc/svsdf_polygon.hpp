@@ -440,7 +440,9 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     const double ext = L + 2.0 * m;
     // every level is 256 x 256 records around the common centre (poly_locate: one index formula); the fine level
     // only fills the central ngs[0] x ngs[0] block of it, the cells its extent covers -- the rest is never looked up
-    const int ng = kPolyGrid, nfill = std::min(kPolyGrid, std::max(2, ngs[l])), lo = (ng - nfill) / 2, hi = lo + nfill;
+    // (nfill even: the filled block must sit symmetrically about the common centre, poly_locate picks the level by the
+    // symmetric radius lr[l] -- an odd value left a half-cell strip of empty records inside it)
+    const int ng = kPolyGrid, nfill = std::min(kPolyGrid, std::max(2, ngs[l] + (ngs[l] & 1))), lo = (ng - nfill) / 2, hi = lo + nfill;
     const double hcell = ext / nfill;
     lv.x0 = 0.5 * (xmin + xmax) - 0.5 * ng * hcell;
     lv.y0 = 0.5 * (ymin + ymax) - 0.5 * ng * hcell;

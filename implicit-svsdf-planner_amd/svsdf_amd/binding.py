@@ -30,7 +30,7 @@ EXPORTS = [
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
     "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline", "svsdf_outline_extrude",
     "svsdf_get_plan", "svsdf_set_plan", "svsdf_set_combine", "svsdf_group_info", "svsdf_debug_sdf_at",
-    "svsdf_group_stripe", "svsdf_set_group_serial",
+    "svsdf_group_stripe", "svsdf_set_group_serial", "svsdf_shape_selfcheck",
 ]
 
 
@@ -627,6 +627,13 @@ class SvsdfContext:
         o = np.zeros(2)
         self._chk(self.L.svsdf_shape_bound(self.ctx, _p(o)), "svsdf_shape_bound")
         return float(o[0]), float(o[1])
+
+    def shape_selfcheck(self):
+        """(R analytic, R sampled, Lipschitz excess: 0 = the shape SDF passed the 1-Lipschitz self-check)."""
+        o = np.zeros(3)
+        self.L.svsdf_shape_selfcheck.argtypes = [C.c_void_p, _dp]
+        self._chk(self.L.svsdf_shape_selfcheck(self.ctx, _p(o)), "svsdf_shape_selfcheck")
+        return float(o[0]), float(o[1]), float(o[2])
 
     def get_plan(self):
         """Launch plan in force (svsdf_get_plan): bound_mode, batches, lanes_per_query, tail_iter, settled."""

@@ -434,6 +434,11 @@ int svsdf_set_group_serial(svsdf_ctx *ctx, int serial);
  * (analytic circumradius of the shape + |offset|, Shape.hpp:281-294 / :531-1476), out2[1] = the largest
  * |q| - sdf_shape(q) found on a polar grid out to 60 m at context creation (self-check: <= out2[0]). */
 int svsdf_shape_bound(const svsdf_ctx *ctx, double out2[2]);
+/* The same two numbers plus out3[2] = the 1-Lipschitz self-check of the shape SDF taken on the same grid at context
+ * creation: 0 when |sdf(q') - sdf(q)| <= |q' - q| held for every sampled pair (true of every exact distance function,
+ * Shape.hpp:531-1476), otherwise the largest excess found -- the context then runs without the value-based second cull
+ * and without the anchor GSIP bound mode, the two devices that rest on that property (same results, more work). */
+int svsdf_shape_selfcheck(const svsdf_ctx *ctx, double out3[3]);
 /* Per-launch HIP-event timing of the dominant (argmin solve) kernel on the library's own
  * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms / solve_ms_sum.
  * enable = 2: additionally runs the point batches one after the other while profiling (a single batch), so that a

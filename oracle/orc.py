@@ -99,7 +99,8 @@ class Oracle:
     """One reference-equivalent (TrajOptimizer + SweptVolumeManager) state on the CPU."""
 
     def __init__(self, shape, safety_hor=0.7, weight_p=60.0, rho=3.8, poly_params=(0.0, 0.0, 0.0),
-                 polygon=None, head_state=None, tail_state=None):
+                 polygon=None, head_state=None, tail_state=None, polygon_loops=None):
+        """polygon_loops: vertex counts of the closed loops `polygon` is made of (None: one loop, the reference's chain)."""
         self.L = lib()
         sid = SHAPE_ID[shape] if isinstance(shape, str) else int(shape)
         pp = _f64(poly_params)
@@ -111,6 +112,11 @@ class Oracle:
         self._ts = np.asfortranarray(ts).ravel(order="F").copy()
         self.ctx = C.c_void_p(self.L.orc_create(sid, _p(pp), _p(poly), 0 if poly is None else len(poly),
                                                 safety_hor, weight_p, rho, _p(self._hs), _p(self._ts)))
+        if polygon_loops is not None and len(polygon_loops) > 1:
+            ls = (C.c_int * len(polygon_loops))(*[int(v) for v in polygon_loops])
+            self.L.orc_set_polygon_loops.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+            if self.L.orc_set_polygon_loops(self.ctx, ls, len(polygon_loops)):
+                raise ValueError("polygon_loops do not fit the vertex list")
         self.N = 0
 
     def __del__(self):

@@ -93,7 +93,21 @@ void orc_shape_init(orc_shape *s, int id, const double poly_params[3], const dou
       s->nverts = 4;
       for (int i = 0; i < 4; ++i) { s->vx[i] = rect[2 * i]; s->vy[i] = rect[2 * i + 1]; }
     }
+    for (int i = 0; i < s->nverts; ++i) s->next[i] = (i + 1) % s->nverts;   /* one closed chain, SHP:1452-1454 */
   }
+}
+
+int orc_shape_set_loops(orc_shape *s, const int *loop_sizes, int nloops) {
+  if (!s || s->id != ORC_SHAPE_Polygon || !loop_sizes || nloops < 1) return -1;
+  int tot = 0;
+  for (int k = 0; k < nloops; ++k) { if (loop_sizes[k] < 3) return -1; tot += loop_sizes[k]; }
+  if (tot != s->nverts) return -1;
+  int b = 0;
+  for (int k = 0; k < nloops; ++k) {
+    for (int i = 0; i < loop_sizes[k]; ++i) s->next[b + i] = b + (i + 1) % loop_sizes[k];
+    b += loop_sizes[k];
+  }
+  return 0;
 }
 
 /* ((pos_rel - trans) * Rotate).head(2): row vector times matrix (e.g. SHP:586).  The z
@@ -325,7 +339,7 @@ static double sdf_polygon(const orc_shape *s, double x, double y, double *cminx,
   double dis_min = 1e9, cx = 0, cy = 0, mx = 0, my = 0;
   int rs = 0;
   for (int i = 0; i < s->nverts; ++i) {
-    int j = (i + 1) % s->nverts;
+    int j = s->next[i];   /* (i + 1) % nverts for the reference's single chain */
     double dis = poly_dis2seg(s->vx[i], s->vy[i], s->vx[j], s->vy[j], x, y, &cx, &cy);
     if (dis < dis_min) { dis_min = dis; mx = cx; my = cy; }
     if (poly_cross_ray(s->vx[i], s->vy[i], s->vx[j], s->vy[j], x, y)) rs++;
@@ -1061,6 +1075,10 @@ void orc_destroy(orc_ctx *ctx) {
   free(ctx->traj.T);
   free(ctx->traj.c);
   free(ctx);
+}
+
+int orc_set_polygon_loops(orc_ctx *ctx, const int *loop_sizes, int nloops) {
+  return ctx ? orc_shape_set_loops(&ctx->shape, loop_sizes, nloops) : -1;
 }
 
 /* minco.getTrajectory MNC:515-528 + SweptVolumeManager::updateTraj SWM:376-385 */

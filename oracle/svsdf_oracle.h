@@ -70,6 +70,12 @@ typedef struct orc_shape {
   double arc_scx, arc_scy;/* sdArc sc = (sin 20, cos 20)                 SHP:1320 */
   int nverts;             /* Polygon only                                SHP:1428-1445 */
   double vx[ORC_MAX_POLY_VERTS], vy[ORC_MAX_POLY_VERTS];
+  /* End vertex of edge i.  The reference's Polygon is ONE closed chain: next[i] = (i + 1) % nverts (SHP:1452-1454).
+   * Its value -- the minimum of dis2Seg over all edges, negated on an odd count of isCrossRayOnXDir over all edges
+   * (SHP:1448-1476) -- does not care how the edges are chained, so a cross-section with several closed loops (a hole, two
+   * solids: BASELINE config 5 says "arbitrary .obj mesh") is the same loop over the union of the loops' edges:
+   * orc_shape_set_loops closes every loop on its own first vertex. */
+  int next[ORC_MAX_POLY_VERTS];
 } orc_shape;
 
 typedef struct orc_traj {
@@ -99,6 +105,9 @@ int  orc_shape_id_from_name(const char *name);            /* -1 -> not registere
 const char *orc_shape_name(int id);
 void orc_shape_init(orc_shape *s, int id, const double poly_params[3],
                     const double *poly_xy, int nverts);
+/* Polygon: the vertex list is nloops closed loops one after the other, loop k holding loop_sizes[k] (>= 3) vertices that
+ * sum to nverts.  Returns 0, or -1 when the sizes do not fit. */
+int orc_shape_set_loops(orc_shape *s, const int *loop_sizes, int nloops);
 double orc_shape_sdf(const orc_shape *s, double x, double y);           /* getonlySDF(pos_rel) */
 void orc_shape_grad(const orc_shape *s, double x, double y, double g[2]);/* getonlyGrad1 */
 
@@ -108,6 +117,7 @@ orc_ctx *orc_create(int shape_id, const double poly_params[3],
                     double safety_hor, double weight_p, double rho,
                     const double head_state[9], const double tail_state[9]);
 void orc_destroy(orc_ctx *ctx);
+int orc_set_polygon_loops(orc_ctx *ctx, const int *loop_sizes, int nloops);   /* orc_shape_set_loops on the context's shape */
 /* MINCO coefficient matrix (6N x 3, COLUMN-major like Eigen::MatrixX3d) + durations. */
 void orc_set_traj(orc_ctx *ctx, int N, const double *coeffs_colmajor, const double *T);
 double orc_traj_duration(const orc_ctx *ctx);

@@ -253,8 +253,10 @@ def test_differential_fuzz(built):
     so it is not part of the blocking set; the seed is printed).  Gates: cost 1e-7, gradient 1e-5 (north_star), basin
     flips 1 %.  A case outside them is admitted ONLY through the sensitivity bracket (round 4): the oracle of record
     re-run with its sin / cos / atan2 results moved by <= 1 ulp (three seeds; no device-library arithmetic involved) must
-    itself move by at least a quarter of the HIP deviation on every violated metric, and the HIP deviation must stay
-    under an absolute ceiling (cost 1e-2, gradients 0.2, flips 10 %).  These are plateaus of SDF(t) -- resting end poses,
+    itself move by AT LEAST the HIP deviation on every violated metric (round 5; round 4 admitted a quarter), and the HIP
+    deviation must stay under an absolute ceiling set to what the campaigns show (cost 1e-6, gradients 1e-3, flips 6 %;
+    round 4: 1e-2 / 0.2 / 10 %).  The admitted fraction goes to the test log as a warning (visible under -q).  These are
+    plateaus of SDF(t) -- resting end poses,
     turn-on-the-spot trajectories -- where the reference's own result depends on the libm it was built with
     (tests/test_plateau_sensitivity.py).  Everything else fails the test."""
     seeds = [7, 20240807, 424243]
@@ -267,8 +269,12 @@ def test_differential_fuzz(built):
         print(f"seed {seed}: worst {worst}")
         assert worst["unexplained"] == 0, out[-4000:]
         total_explained += worst["libm_explained"]
-    print(f"fuzz: {total_explained} of {40 * len(seeds)} cases outside the gates, all inside the 1-ulp bracket of the oracle")
-    assert total_explained <= 0.15 * 40 * len(seeds)   # plateaus are rare, not the rule (fresh 200-case campaigns: 1.5 % and 5 %)
+    msg = (f"differential fuzz: {total_explained} of {40 * len(seeds)} cases ({100.0 * total_explained / (40 * len(seeds)):.1f} %) outside the "
+           f"gates, all admitted through the 1-ulp bracket of the oracle (ratio >= 1, ceilings 1e-6 / 1e-3 / 6 %); 0 unexplained")
+    print(msg)
+    import warnings
+    warnings.warn(msg)   # (shows in the -q summary: the GPUTEST tail carries the admitted fraction)
+    assert total_explained <= 0.10 * 40 * len(seeds)   # plateaus are rare, not the rule (fresh 200-case campaigns: 1.5 % and 5 %)
     # the round-1 arithmetic (forced) on the first seed: inside the old, looser gate only
     worst_fast, out = _fuzz(40, 7, FUZZ_DEGENERATE="0", FUZZ_PIECE_TIME="fast")
     assert worst_fast["cost"] <= 1e-7 and worst_fast["gC"] <= 1e-4, out[-2000:]

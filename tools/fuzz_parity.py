@@ -7,9 +7,10 @@ that oracle bit for bit).  The oracle of record (glibc sin / cos / atan2) is re-
 by -1 / 0 / +1 ulp per argument (orc.set_trig_perturb, three seeds): another libm the reference could have been built
 with.  These runs know nothing of the ROCm device library.  A case is `libm_explained` only if, on EVERY violated metric,
 the largest deviation among the perturbed oracles (from the oracle of record) is at least BRACKET x the HIP deviation
-(BRACKET = 0.25: on a plateau of SDF(t) the size of the jump depends on which basin the argmin lands in, so the
-deviations scatter, but a <= 1 ulp change of the trig must be able to move the reference's OWN answer by a comparable
-amount) and the HIP deviation stays under an absolute ceiling (cost 1e-2, gradients 0.2, flips 10 %).  Anything else is
+(BRACKET = 1 since round 5: a <= 1 ulp change of the trig must move the reference's OWN answer by at least as much as the
+HIP path deviates; round 4 admitted a quarter) and the HIP deviation stays under an absolute ceiling set to what the
+campaigns actually show (cost 1e-6, gradients 1e-3, flips 6 %; round 4: 1e-2 / 0.2 / 10 % -- four orders of magnitude
+above anything observed).  Anything else is
 `unexplained` and is what tests/test_gpu_parity.py::test_differential_fuzz fails on.  The device-trig oracle's deviation
 is still printed (it equals the HIP deviation when the kernels are right).
 usage: fuzz_parity.py [cases] [seed]   env FUZZ_DEGENERATE=0|1 (default 1), FUZZ_DEVICE_TRIG, FUZZ_PIECE_TIME"""
@@ -104,9 +105,9 @@ for case in range(ncase):
                 o.set_trig_perturb(1000 * seed0 + 10 * case + ps)
                 br = [max(a, b) for a, b in zip(br, dev_of(o.penalty(pts, nthreads=NT, sum_mode=1, per_point=True)))]
             o.set_modes(0, 0)
-            BR = 0.25
+            BR = float(os.environ.get("FUZZ_BRACKET", "1.0"))
             ok = ((rc <= 1e-7 or br[0] >= BR * rc) and (rC <= 1e-5 or br[1] >= BR * rC) and (rT <= 1e-5 or br[2] >= BR * rT) and
-                  (flips <= 0.01 or br[3] + 0.5 / P >= BR * flips) and rc <= 1e-2 and rC <= 0.2 and rT <= 0.2 and flips <= 0.10)
+                  (flips <= 0.01 or br[3] + 0.5 / P >= BR * flips) and rc <= 1e-6 and rC <= 1e-3 and rT <= 1e-3 and flips <= 0.06)
             verdict = "libm_explained" if ok else "UNEXPLAINED"
             worst["libm_explained" if ok else "unexplained"] += 1
             if not ok:
@@ -118,4 +119,5 @@ for case in range(ncase):
         print(f"CASE {case} seed {seed0} shape {shape} pp {np.round(pp, 3)} N {N} kind {kind} sh {sh:.3f}: cost {cost:.9g} vs {ocost:.9g} "
               f"(rel {rc:.2e}) gC {rC:.2e} gT {rT:.2e} flips {flips:.3f} interior {int((osdf <= 0).sum())} -> {verdict}", flush=True)
     ctx.close()
-print(f"{ncase} cases, {bad} outside the gates, worst {worst}, {time.time() - t00:.1f} s")
+print(f"{ncase} cases, {bad} outside the gates (admitted through the 1-ulp bracket: {worst['libm_explained']} = {100.0 * worst['libm_explained'] / max(ncase, 1):.1f} %, "
+      f"unexplained: {worst['unexplained']}), worst {worst}, {time.time() - t00:.1f} s")

@@ -5,7 +5,7 @@
 #   probe        tools/state_probe.py (workload timing vs process state)
 #   refscale     bench.py --only reference_scale
 #   reftrace     rocprofv3 kernel trace + per-launch timeline of a reference-scale callback (star map)
-#   site:<lib>   tools/site_stats.py of a -DSVSDF_SITE_STATS variant build on C3,NS
+#   site:<lib>[:<configs>]   tools/site_stats.py of a -DSVSDF_SITE_STATS variant build (default C3,NS; ref:star = reference scale)
 #   bench        bench.py default line (N = 1)
 #   benchq       bench.py --no-extras --no-cpu-baseline (headline only)
 #   stripes8     bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config C4 (8 stripes on this GPU)
@@ -33,7 +33,7 @@ for STEP in "$@"; do
        KT=$(find /tmp/rt_$TAG -name '*kernel_trace.csv' | head -1); KS=$(find /tmp/rt_$TAG -name '*kernel_stats.csv' | head -1)
        [ -n "$KS" ] && cp $KS $OUT/${TAG}_reftrace_kernel_stats.csv
        [ -n "$KT" ] && python $ROOT/tools/timeline.py $KT 9 > $OUT/${TAG}_reftrace_timeline.txt 2>&1) ;;
-    site)     timeout 400 python -u tools/site_stats.py ${ARG:-st} C3,NS > $OUT/${TAG}_site_${ARG:-st}.txt 2>&1 ;;
+    site)     IFS=: read -r V C <<< "$ARG"; timeout 400 python -u tools/site_stats.py ${V:-st} ${C:-C3,NS} > $OUT/${TAG}_site_${V:-st}.txt 2>&1 ;;
     bench)    timeout 900 python -u bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err ;;
     benchq)   timeout 300 python -u bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_quick.json 2> $OUT/${TAG}_bench_quick.err ;;
     stripes8) timeout 600 python -u bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config C4 --steps 10 --no-extras > $OUT/${TAG}_stripes8.json 2> $OUT/${TAG}_stripes8.err ;;

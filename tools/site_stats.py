@@ -18,7 +18,13 @@ from svsdf_amd import workload  # noqa: E402
 cfgs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["C3", "NS"]
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 1000000
 for cfg in cfgs:
-    w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
+    if cfg.startswith("ref:"):   # reference-scale case (demo map through the producer, 24 pieces, generic durations)
+        w = workload.reference_case(cfg[4:], N=24)
+        T = svsdf_amd.forward_T(w["xs"][0][:24])
+        w["T"] = T
+        w["coeffs"] = svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], w["xs"][0][24:].reshape(-1, 3), T)
+    else:
+        w = workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs)
     c = svsdf_amd.SvsdfContext(shape=w["shape"], safety_hor=w["safety_hor"], weight_p=w["weight_p"], rho=w["rho"],
                                poly_params=w["poly_params"], polygon=w["polygon"], head_state=w["head_state"],
                                tail_state=w["tail_state"], device=0)
