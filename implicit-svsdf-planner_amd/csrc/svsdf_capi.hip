@@ -209,8 +209,17 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
       hipMalloc((void **)&ctx->d_nonfinite, sizeof(int)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_sums, kOutPartial * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_out, kOutDoubles * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void **)&ctx->h_out, kOutDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
+      hipHostMalloc((void **)&ctx->h_out, kOutDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_ticket, sizeof(unsigned)) != hipSuccess)
     return bail("device allocation failed");
+  if (hipMemsetAsync(ctx->d_ticket, 0, sizeof(unsigned), ctx->stream) != hipSuccess) return bail("hipMemset failed");
+  {  // the pinned result buffer as the device sees it: k_reduce's last block writes the evaluation's result there directly
+     // (SVSDF_HOST_WRITE=0: a device-to-host copy command instead, as before round 5)
+    void *dp = nullptr;
+    const char *e = std::getenv("SVSDF_HOST_WRITE");
+    if (!(e && std::atoi(e) == 0) && hipHostGetDevicePointer(&dp, ctx->h_out, 0) == hipSuccess) ctx->h_out_dev = (double *)dp;
+    (void)hipGetLastError();
+  }
   // (on the context's own stream: it is non-blocking, a null-stream memset would not be ordered with its kernels)
   if (hipMemsetAsync(ctx->d_ctl, 0, kMaxBatches * sizeof(BatchCtl) + 8 * 8 * (kMaxIter + 4), ctx->stream) != hipSuccess) return bail("hipMemset failed");
   {  // shape bound radius R with sdf_shape(q) >= |q| - R for every q: the shape's circumradius about the body origin
@@ -258,7 +267,7 @@ void svsdf_destroy(svsdf_ctx *ctx) {
                   ctx->gs.list[0], ctx->gs.list[1], ctx->gs.solve, ctx->gs.sqx, ctx->gs.sqy, ctx->gs.sqth,
                   ctx->gs.sq_ub, ctx->gs.sq_k, ctx->gs.sq_sdf, ctx->gs.sq_t, ctx->d_ctl,
                   ctx->d_block_partials, ctx->d_sums,
-                  ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_flag};
+                  ctx->d_out, ctx->d_nonfinite, ctx->d_fe, ctx->d_fe_flag, ctx->d_ticket};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_in) (void)hipHostFree(ctx->h_in);

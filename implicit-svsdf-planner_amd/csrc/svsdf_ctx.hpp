@@ -167,6 +167,8 @@ struct svsdf_ctx {
   double *d_sums = nullptr;       // 19 * kMaxPieces + 1
   double *d_out = nullptr;        // [partial (19 * kMaxPieces + 1) | 8 x u64 stats]
   double *h_out = nullptr;        // pinned mirror
+  double *h_out_dev = nullptr;    // the same buffer as the device addresses it (k_reduce writes the result there); null: copy
+  unsigned *d_ticket = nullptr;   // k_reduce: finished-block counter (zero between launches)
   int *d_nonfinite = nullptr;
   int h_nonfinite = 0;
   size_t e_end = 0;

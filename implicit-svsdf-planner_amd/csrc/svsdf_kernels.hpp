@@ -443,8 +443,9 @@ __device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp,
 __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, int exact,
                        TrajDev *__restrict__ tr, Pose *__restrict__ pose,
                        Chunk *__restrict__ chunks, double r_bound, BatchCtl *__restrict__ ctl,
-                       int nbatch) {
+                       int nbatch, int *__restrict__ nonfinite) {
   extern __shared__ double prep_lds[];
+  if (threadIdx.x == 0 && nonfinite) *nonfinite = 0;   // (was a memset node of its own in front of every evaluation)
   const double *coeffs = in, *T = in + 18 * N, *tk = in + 19 * N, *slack = in + 19 * N + K;
   for (int b = threadIdx.x; b < nbatch; b += blockDim.x) {
     BatchCtl &c = ctl[b];
@@ -2258,19 +2259,17 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
 }
 
 #ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_pipeline.hip
-__global__ void __launch_bounds__(kBlock)
-k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
+__device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
            const double *__restrict__ res_t, const double *__restrict__ res_gx,
            const double *__restrict__ res_gy, double safety_hor, double weight_p,
-           double *__restrict__ block_partials, int *__restrict__ nonfinite) {
+           double *__restrict__ block_partials, int *__restrict__ nonfinite, double *asm_lds) {
   // Deterministic (bit-reproducible run to run): no floating-point atomics.  Every wave owns a private
   // accumulator row in LDS; per grid-stride step the wave walks the distinct piece ids among its active lanes
   // (lowest lane first), sums each of the 20 per-point terms of that piece with a fixed xor butterfly (every
   // lane ends with the same bits) and lane 0 adds the totals to the wave's row.  The point -> (block, wave, lane,
   // step) assignment depends on P and the grid only; rows are then summed in wave order, block partials in block
   // order (k_final).  Morton-sorted neighbours share their piece, so a wave sees 1-3 distinct ids per step.
-  extern __shared__ double asm_lds[];
   const TrajL tr = stage_traj(trg, asm_lds);
   const int N = tr.N;
   const int plen = 19 * N + 1;
@@ -2340,14 +2339,22 @@ k_assemble(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
       const int src = __ffsll((long long)m) - 1;
       const int i0 = __shfl(i, src, 64);
       const bool sel = act && (i == i0);
+      // the 20 butterflies advance together, one exchange step at a time (round 5): twenty independent dependent chains
+      // of cross-lane exchanges instead of one after the other -- a small cloud's wave holds a dozen distinct pieces and
+      // spent 46 us here for 101 points.  Same partners, same order of additions per entry: same bits.
+      double s[20];
 #pragma unroll
-      for (int q = 0; q < 20; ++q) {
-        double s = sel ? v[q] : 0.0;
+      for (int q = 0; q < 20; ++q) s[q] = sel ? v[q] : 0.0;
 #pragma unroll
-        for (int x = 1; x <= 32; x <<= 1) s += __shfl_xor(s, x, 64);
-        if (lane == 0) {
+      for (int x = 1; x <= 32; x <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 20; ++q) s[q] += __shfl_xor(s[q], x, 64);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
           const int e = (q == 0) ? 0 : (q == 19) ? (1 + 18 * N + i0) : (1 + ((q - 1) / 6) * 6 * N + 6 * i0 + (q - 1) % 6);
-          acc[e] += s;
+          acc[e] += s[q];
         }
       }
       m &= ~__ballot(sel);
@@ -2376,44 +2383,111 @@ k_final(const double *__restrict__ block_partials, int nblocks, double *__restri
 
 // partial = [cost, gradC (18N), gradT (N)] with gradT[j] = sum_{i > j} hist[i] (BEO:859-862);
 // also gathers the per-batch counters.
-__global__ void k_finish(const double *__restrict__ sums, int N, double *__restrict__ partial,
-                         const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
-                         const int *__restrict__ nonfinite, unsigned long long *__restrict__ stats_out) {
+__device__ __forceinline__ void finish_body(const double *__restrict__ sums, int N, double *__restrict__ partial,
+                                            const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
+                                            const int *__restrict__ nonfinite, unsigned long long *__restrict__ stats_out) {
   for (int k = threadIdx.x; k <= 18 * N; k += blockDim.x) partial[k] = sums[k];
   if (threadIdx.x == 0) {
     double suf = 0.0;
     for (int j = N - 1; j >= 0; --j) { partial[1 + 18 * N + j] = suf; suf += sums[1 + 18 * N + j]; }
-    unsigned long long so = 0, ev = 0, sc = 0, in = 0, nf = (unsigned long long)*nonfinite, rem = 0, seeded = 0, iters = 0, cu = 0, rs = 0, sp_ = 0;
+  }
+  if (threadIdx.x < 64) {
+    // the counters, gathered by the first wave (round 5: one thread used to walk nbatch x 32 slots x 6 words and three
+    // per-iteration arrays on its own -- 13 us of a 490 us reference-scale callback): lane k takes stat slot k (k < 32) and
+    // GSIP iteration k (k < kMaxIter); integer sums, so the order is free
+    const int lane = (int)threadIdx.x;
+    unsigned long long so = 0, ev = 0, sc = 0, cu = 0, rs = 0, sp_ = 0, seeded = 0, iters = 0, ns = 0, na = 0;
     for (int b = 0; b < nbatch; ++b) {
-      for (int k = 0; k < kStatSlots; ++k) {
-        const StatSlot &ss = ctl[b].stat[k];
+      if (lane < kStatSlots) {
+        const StatSlot &ss = ctl[b].stat[lane];
         so += ss.solves; ev += ss.evals; sc += ss.scan; cu += ss.culled; rs += ss.round_scan; sp_ += ss.spec;
       }
-      in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
-      rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
-      for (int i = 0; i <= it_end; ++i) {
-        seeded += (unsigned long long)ctl[b].n_seed[i];
-        if (ctl[b].n_solve[i] > 0 && (unsigned long long)(i + 1) > iters) iters = (unsigned long long)(i + 1);
+      if (lane < kMaxIter) {
+        ns += (unsigned long long)ctl[b].n_solve[lane];
+        na += (unsigned long long)ctl[b].n_active[lane];
+      }
+      if (lane <= it_end && lane < kMaxIter + 2) {
+        seeded += (unsigned long long)ctl[b].n_seed[lane];
+        if (ctl[b].n_solve[lane] > 0 && (unsigned long long)(lane + 1) > iters) iters = (unsigned long long)(lane + 1);
       }
     }
-    stats_out[0] = so; stats_out[1] = ev; stats_out[2] = sc; stats_out[3] = in; stats_out[4] = nf;
-    stats_out[5] = rem; stats_out[6] = seeded; stats_out[7] = iters; stats_out[8] = cu;
-    for (int i = 0; i < kMaxIter; ++i) {   // solves per GSIP iteration: the host sizes the next evaluation's lane groups
-      unsigned long long ns = 0;
-      for (int b = 0; b < nbatch; ++b) ns += (unsigned long long)ctl[b].n_solve[i];
-      stats_out[9 + i] = ns;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      so += __shfl_xor(so, m, 64); ev += __shfl_xor(ev, m, 64); sc += __shfl_xor(sc, m, 64); cu += __shfl_xor(cu, m, 64);
+      rs += __shfl_xor(rs, m, 64); sp_ += __shfl_xor(sp_, m, 64); seeded += __shfl_xor(seeded, m, 64);
+      const unsigned long long oi = __shfl_xor(iters, m, 64);
+      iters = (oi > iters) ? oi : iters;
     }
-    stats_out[9 + kMaxIter] = rs;
-    stats_out[10 + kMaxIter] = sp_;
-    stats_out[11 + 2 * kMaxIter] = (unsigned long long)ctl[0].n_int;   // interior points found (may exceed the capacity: repeat)
-    stats_out[12 + 2 * kMaxIter] = ctl[0].clk[0];                       // clock probe of batch 0's main solve (BatchCtl::clk)
-    stats_out[13 + 2 * kMaxIter] = ctl[0].clk[1];
-    for (int i = 0; i < kMaxIter; ++i) {   // active GSIP points per iteration: the host places the fused tail (k_tail) by them
-      unsigned long long na = 0;
-      for (int b = 0; b < nbatch; ++b) na += (unsigned long long)ctl[b].n_active[i];
-      stats_out[11 + kMaxIter + i] = na;
+    if (lane < kMaxIter) {
+      stats_out[9 + lane] = ns;                  // solves per GSIP iteration: the host sizes the next evaluation's lane groups
+      stats_out[11 + kMaxIter + lane] = na;      // active GSIP points per iteration: the host places the fused tail (k_tail) by them
+    }
+    if (lane == 0) {
+      unsigned long long in = 0, nf = (unsigned long long)__hip_atomic_load(nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), rem = 0;
+      for (int b = 0; b < nbatch; ++b) {
+        in += (unsigned long long)ctl[b].n_active[0]; nf += (unsigned long long)ctl[b].nonfinite;
+        rem += (unsigned long long)ctl[b].n_solve[it_end];    // > 0: solves requested but not run yet
+      }
+      stats_out[0] = so; stats_out[1] = ev; stats_out[2] = sc; stats_out[3] = in; stats_out[4] = nf;
+      stats_out[5] = rem; stats_out[6] = seeded; stats_out[7] = iters; stats_out[8] = cu;
+      stats_out[9 + kMaxIter] = rs;
+      stats_out[10 + kMaxIter] = sp_;
+      stats_out[11 + 2 * kMaxIter] = (unsigned long long)ctl[0].n_int;   // interior points found (may exceed the capacity: repeat)
+      stats_out[12 + 2 * kMaxIter] = ctl[0].clk[0];                       // clock probe of batch 0's main solve (BatchCtl::clk)
+      stats_out[13 + 2 * kMaxIter] = ctl[0].clk[1];
     }
   }
+}
+
+__global__ void k_finish(const double *__restrict__ sums, int N, double *__restrict__ partial,
+                         const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
+                         const int *__restrict__ nonfinite, unsigned long long *__restrict__ stats_out) {
+  finish_body(sums, N, partial, ctl, nbatch, it_end, nonfinite, stats_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reduce (round 5): assembly + block reduction (assemble_body), then -- in the block that finishes LAST -- the fixed-order
+// sum of the block partials (what k_final did: entry e by one wave, lane b takes blocks b, b + 64, ..., xor butterfly) and
+// k_finish's suffix sum / counter gathering, and the result written both to the device buffer (collectives read it there) and
+// straight into the pinned host buffer: one launch and no copy command where the evaluation's tail was three launches and a
+// device-to-host copy (64 us + 10 us of the 490 us a reference-scale callback took).  Same additions in the same order as the
+// three kernels: same bits.  `ticket` counts finished blocks; the last block resets it.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_reduce(const TrajDev *__restrict__ trg, const double *__restrict__ px_, const double *__restrict__ py_, int P,
+         const double *__restrict__ res_sdf, const double *__restrict__ res_t, const double *__restrict__ res_gx,
+         const double *__restrict__ res_gy, double safety_hor, double weight_p, double *__restrict__ block_partials,
+         int *__restrict__ nonfinite, double *__restrict__ out, const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
+         int out_partial, int out_doubles, unsigned *__restrict__ ticket, double *__restrict__ host_out) {
+  extern __shared__ double asm_lds[];
+  __shared__ unsigned s_last;
+  assemble_body(trg, px_, py_, P, res_sdf, res_t, res_gx, res_gy, safety_hor, weight_p, block_partials, nonfinite, asm_lds);
+  __threadfence();   // this block's partials (and its non-finite count) are visible device-wide before its ticket is
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int N = trg->N;
+  const int plen = 19 * N + 1;
+  const int nblocks = (int)gridDim.x;
+  double *sums = asm_lds + traj_lds_doubles(N);   // (the accumulator rows are free again: plen <= 4 plen doubles)
+  const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+  for (int e = wv; e < plen; e += kBlock / 64) {
+    double s = 0.0;
+    // (other blocks wrote these: read at device scope, past this CU's vector cache)
+    for (int b = lane; b < nblocks; b += 64) s += __hip_atomic_load(&block_partials[(size_t)e * nblocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) sums[e] = s;
+  }
+  __syncthreads();
+  finish_body(sums, N, out, ctl, nbatch, it_end, nonfinite, reinterpret_cast<unsigned long long *>(out + out_partial));
+  __threadfence();
+  __syncthreads();
+  if (host_out)
+    for (int k = threadIdx.x; k < out_doubles; k += blockDim.x) host_out[k] = out[k];
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -297,7 +297,7 @@ void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
 
 // Upload (coeffs, T), update traj_duration like SweptVolumeManager::updateTraj (SWM:376-385),
 // build the layer-1 time grid exactly like the reference's accumulating loop (SWM:567).
-int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
+int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bool clear_nonfinite = false) {
   if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 64]");
   double td = 0.0;
   for (int i = 0; i < N; ++i) td += T[i];  // Trajectory::getTotalDuration (TRJ:410-419)
@@ -417,22 +417,28 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T) {
   const size_t lds = (size_t)traj_lds_doubles(N) * sizeof(double);
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), lds, ctx->stream, ctx->d_in, N, dur, (int)K,
                      ctx->piece_time_mode, ctx->d_traj,
-                     ctx->d_pose, ctx->d_chunks, ctx->r_bound, ctx->d_ctl, ctx->nbatch);
+                     ctx->d_pose, ctx->d_chunks, ctx->r_bound, ctx->d_ctl, ctx->nbatch, clear_nonfinite ? ctx->d_nonfinite : nullptr);
   return SVSDF_OK;
 }
 
+
+// The stream batch b's chain runs on: its own, or -- with a single batch -- the main stream (round 5: a one-batch evaluation
+// used to hop main -> batch -> main through two events, ~12 us each on the device timeline; a reference-scale callback is
+// ~20 launches of a few us)
+hipStream_t batch_stream(const svsdf_ctx *ctx, int b) { return ctx->nbatch > 1 ? ctx->bstream[b] : ctx->stream; }
 
 int join_batches(svsdf_ctx *ctx) {
   if (!ctx->launch_err.empty()) {   // a launch that could not be made: a clear error instead of a raw HIP launch failure
     const std::string m = ctx->launch_err;
     ctx->launch_err.clear();
-    for (int b = 0; b < ctx->nbatch; ++b) (void)hipStreamSynchronize(ctx->bstream[b]);
+    for (int b = 0; b < ctx->nbatch; ++b) (void)hipStreamSynchronize(batch_stream(ctx, b));
     return fail(ctx, SVSDF_ERR_INVALID, m);
   }
-  for (int b = 0; b < ctx->nbatch; ++b) {
-    HIPCHK(hipEventRecord(ctx->ev_done[b], ctx->bstream[b]));
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
-  }
+  if (ctx->nbatch > 1)
+    for (int b = 0; b < ctx->nbatch; ++b) {
+      HIPCHK(hipEventRecord(ctx->ev_done[b], ctx->bstream[b]));
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
+    }
   HIPCHK(hipGetLastError());
   return SVSDF_OK;
 }
@@ -443,7 +449,7 @@ int join_batches(svsdf_ctx *ctx) {
 // enqueue_solve_round(i) enqueues S_i then R_(i+1).
 void enqueue_solve_round(svsdf_ctx *ctx, int it, bool tail_next = false) {
   for (int b = 0; b < ctx->nbatch; ++b) {
-    hipStream_t st = ctx->bstream[b];
+    hipStream_t st = batch_stream(ctx, b);
     BatchCtl *ctl = ctx->d_ctl + b;
     QuerySet q{};
     q.qx = ctx->gs.sqx; q.qy = ctx->gs.sqy; q.count_ptr = &ctl->n_solve[it];
@@ -481,15 +487,15 @@ int enqueue_queries(svsdf_ctx *ctx, int N, const double *coeffs, const double *T
   ctx->stats.points = ctx->P;
   const size_t e_begin = next_event(ctx);
   (void)hipEventRecord(ctx->ev_pool[e_begin], ctx->stream);
-  int rc = upload_traj(ctx, N, coeffs, T);
+  int rc = upload_traj(ctx, N, coeffs, T, /*clear_nonfinite=*/true);   // (k_prep also clears the non-finite counter)
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int), ctx->stream));
-  HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
+  const bool fork = ctx->nbatch > 1;   // one batch: the whole chain stays on the main stream (no cross-stream hand-offs)
+  if (fork) HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
   const int m = ctx->tail_iter = choose_tail_iter(ctx);
   for (int b = 0; b < ctx->nbatch; ++b) {
-    hipStream_t st = ctx->bstream[b];
+    hipStream_t st = batch_stream(ctx, b);
     BatchCtl *ctl = ctx->d_ctl + b;
-    HIPCHK(hipStreamWaitEvent(st, ctx->ev_prep, 0));
+    if (fork) HIPCHK(hipStreamWaitEvent(st, ctx->ev_prep, 0));
     QuerySet qm{};
     qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
     qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
@@ -526,10 +532,10 @@ int swept_field(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, do
   ctx->stats.points = ctx->P;
   int rc = upload_traj(ctx, N, coeffs, T);
   if (rc) return rc;
-  HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
+  if (ctx->nbatch > 1) HIPCHK(hipEventRecord(ctx->ev_prep, ctx->stream));
   for (int b = 0; b < ctx->nbatch; ++b) {
-    hipStream_t st = ctx->bstream[b];
-    HIPCHK(hipStreamWaitEvent(st, ctx->ev_prep, 0));
+    hipStream_t st = batch_stream(ctx, b);
+    if (ctx->nbatch > 1) HIPCHK(hipStreamWaitEvent(st, ctx->ev_prep, 0));
     QuerySet qm{};
     qm.qx = ctx->d_px; qm.qy = ctx->d_py; qm.stride = 0; qm.count_ptr = nullptr;
     qm.count_fixed = ctx->bcount[b]; qm.list = nullptr; qm.base = ctx->bstart[b]; qm.n_outer = 1;
@@ -545,6 +551,7 @@ int swept_field(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, do
 // assemble + reduce + k_finish on the main stream, one D2H of [partial | counters], sync.
 int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
   const int N = ctx->N;
+  bool host_written = false;
   if (with_partial) {
     const unsigned grid = (unsigned)std::min<size_t>((ctx->P + kBlock - 1) / kBlock, 512);
     const size_t plen = 19 * (size_t)N + 1;
@@ -554,20 +561,22 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
       ctx->block_partials_cap = (size_t)grid * plen;
     }
     const size_t lds = ((size_t)traj_lds_doubles(N) + (kBlock / 64) * plen) * sizeof(double);  // one accumulator row per wave
-    hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
+    // assembly, block reduction, fixed-order final sum, suffix sum and counters in ONE launch; the last block writes the
+    // result to the device buffer and straight into the pinned host buffer (k_reduce)
+    hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
                        (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                       ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite);
-    hipLaunchKernelGGL(k_final, dim3((unsigned)plen), dim3(64), 0, ctx->stream, ctx->d_block_partials, (int)grid,
-                       ctx->d_sums);
+                       ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite, ctx->d_out,
+                       ctx->d_ctl, ctx->nbatch, ctx->it_done, (int)kOutPartial, (int)kOutDoubles, ctx->d_ticket, ctx->h_out_dev);
+    host_written = ctx->h_out_dev != nullptr;
   } else {
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, kOutPartial * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
+                       ctx->nbatch, ctx->it_done, ctx->d_nonfinite,
+                       reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
   }
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
-                     ctx->nbatch, ctx->it_done, ctx->d_nonfinite,
-                     reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
   ctx->e_end = next_event(ctx);
   (void)hipEventRecord(ctx->ev_pool[ctx->e_end], ctx->stream);
-  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (!host_written) HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return SVSDF_OK;

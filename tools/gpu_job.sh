@@ -14,6 +14,7 @@
 #   fuzz:<cases>:<seed>   tools/fuzz_parity.py campaign
 #   kt:<config>  rocprofv3 --kernel-trace --stats of the bench command on one config, one batch (SVSDF_BATCHES=1) + timeline
 #   pmc:<config> separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*) of the same command -> tools/pmc_summary.py
+#   pmcref[:<map>]  PMC passes (instruction mix, wave cycles, instruction cache) of reference-scale callbacks
 #   smoke        __graft_entry__.smoke()
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -51,6 +52,13 @@ for STEP in "$@"; do
          timeout 400 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $D -o p -- python -u $ROOT/tools/prof_eval.py $ARG $(python -c "import sys; sys.path[:0]=['$ROOT/tools']; from svsdf_cfg import default_points; print(default_points('$ARG'))") 6 > /tmp/pmc.log 2>&1
        done
        python $ROOT/tools/pmc_agg.py $(find /tmp/pmc_${TAG}_* -name '*counter_collection.csv') > $OUT/${TAG}_pmc_$ARG.txt 2>&1) ;;
+    pmcref)
+      (cd /tmp && rocprofv3 -L > $OUT/${TAG}_counters_available.txt 2>&1
+       for CTR in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INSTS_FLAT"; do
+         D=/tmp/pmcref_${TAG}_$(echo $CTR | tr ' ' '_'); rm -rf $D
+         timeout 200 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $D -o p -- python -u $ROOT/tools/ref_trace.py ${ARG:-star} 12 > /tmp/pmcref.log 2>&1 || tail -3 /tmp/pmcref.log
+       done
+       python $ROOT/tools/pmc_agg.py $(find /tmp/pmcref_${TAG}_* -name '*counter_collection.csv') > $OUT/${TAG}_pmcref_${ARG:-star}.txt 2>&1) ;;
     smoke)    timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.txt 2>&1; tail -2 $OUT/${TAG}_smoke.txt ;;
     *) echo "unknown step $STEP" ;;
   esac
