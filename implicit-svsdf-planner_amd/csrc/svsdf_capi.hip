@@ -83,6 +83,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     svsdf_ctx *h = new svsdf_ctx();
     h->cfg = *cfg;
     h->cfg.polygon_xy = nullptr;
+    h->cfg.polygon_loop_sizes = nullptr;
     h->host_only = true;
     return h;
   }
@@ -96,6 +97,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   svsdf_ctx *ctx = new svsdf_ctx();
   ctx->cfg = *cfg;
   ctx->cfg.polygon_xy = nullptr;
+  ctx->cfg.polygon_loop_sizes = nullptr;
   int dev = cfg->device;
   if (dev < 0) (void)hipGetDevice(&dev);
   ctx->device = dev;
@@ -140,17 +142,27 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   sp.edges = nullptr;
   if (cfg->shape_id == SVSDF_SHAPE_Polygon) {
     std::vector<double> &v = ctx->poly_xy;
+    std::vector<int> &loops = ctx->poly_loops;
+    loops.clear();
     if (cfg->polygon_xy && cfg->polygon_nverts >= 3) {
-      if (cfg->polygon_nverts > SVSDF_MAX_POLY_VERTS)
-        return bail("svsdf_create: polygon_nverts exceeds SVSDF_MAX_POLY_VERTS (" + std::to_string(SVSDF_MAX_POLY_VERTS) + ")");
+      const int nl = (cfg->polygon_loop_sizes && cfg->polygon_nloops >= 2) ? cfg->polygon_nloops : 0;
+      if ((long long)cfg->polygon_nverts + nl > SVSDF_MAX_POLY_VERTS)
+        return bail("svsdf_create: polygon_nverts (+ one entry per loop) exceeds SVSDF_MAX_POLY_VERTS (" + std::to_string(SVSDF_MAX_POLY_VERTS) + ")");
       v.assign(cfg->polygon_xy, cfg->polygon_xy + 2 * (size_t)cfg->polygon_nverts);
+      if (nl) {
+        long long tot = 0;
+        for (int k = 0; k < nl; ++k) { if (cfg->polygon_loop_sizes[k] < 3) return bail("svsdf_create: a polygon loop needs at least 3 vertices"); tot += cfg->polygon_loop_sizes[k]; }
+        if (tot != cfg->polygon_nverts) return bail("svsdf_create: polygon_loop_sizes do not add up to polygon_nverts");
+        loops.assign(cfg->polygon_loop_sizes, cfg->polygon_loop_sizes + nl);
+      }
     } else {
       v = {6, -0.1, 6, 0.1, -6, 0.1, -6, -0.1};  // SWM:363-369
     }
     // candidate lists of the outline (svsdf_polygon.hpp), then one upload: the header's pointers are device addresses
     PolyAccelHost pa;
     const int ngf = 128, ngc = 256;   // grid cells per side, fine / coarse
-    if (!build_poly_accel(v.data(), (int)(v.size() / 2), pa, ngf, ngc)) return bail("svsdf_create: polygon outline rejected (non-finite vertex?)");
+    if (!build_poly_accel(v.data(), (int)(v.size() / 2), pa, ngf, ngc, 256, SVSDF_POLY_REFINE, 32, loops.empty() ? nullptr : loops.data(), (int)loops.size()))
+      return bail("svsdf_create: polygon outline rejected (non-finite vertex?)");
     auto align = [](size_t o) { return (o + 63) & ~(size_t)63; };
     const size_t o_edges = align(sizeof(PolyAccel));
     const size_t o_cell = align(o_edges + pa.edges.size() * sizeof(PolyEdge));
@@ -170,13 +182,14 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
     if (!pa.over.empty()) std::memcpy(blob.data() + o_over, pa.over.data(), pa.over.size() * sizeof(unsigned short));
     if (hipMemcpy(ctx->d_poly, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess)
       return bail("hipMemcpy polygon failed");
-    sp.nverts = (int)(v.size() / 2);
+    sp.nverts = (int)pa.edges.size();   // entries of the edge array: the vertices + one closing copy per loop of a multi-loop outline
     sp.accel = reinterpret_cast<const PolyAccel *>(ctx->d_poly);
     sp.edges = pa.hdr.edges;
     // the solve / round kernels keep outlines of up to 1024 edges (48 KB) in LDS in front of the pose table
     ctx->poly_lds = sp.nverts <= kPolyLdsMaxVerts;
     if (const char *e = std::getenv("SVSDF_POLY_LDS")) ctx->poly_lds = ctx->poly_lds && std::atoi(e) != 0;
-    ctx->cfg.polygon_nverts = sp.nverts;
+    ctx->cfg.polygon_nverts = (int)(v.size() / 2);
+    ctx->cfg.polygon_nloops = (int)loops.size();
   }
   ctx->G_env = 0;
   if (const char *e = std::getenv("SVSDF_G")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) { ctx->G_env = g; ctx->G = g; ctx->G_late = std::max(g, 8); } }
@@ -225,7 +238,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   {  // shape bound radius R with sdf_shape(q) >= |q| - R for every q: the shape's circumradius about the body origin
      // (analytic, per shape; shape_circumradius above) plus the length of its offset (Shape.hpp:281-294).  The polar
      // sample of |q| - sdf(q) (k_rbound, out to 60 m) is kept as a self-check of that bound, not as its source.
-    const double r0 = shape_circumradius(cfg->shape_id, ctx->poly_xy.data(), sp.nverts);
+    const double r0 = shape_circumradius(cfg->shape_id, ctx->poly_xy.data(), (int)(ctx->poly_xy.size() / 2));
     const double analytic = (r0 + std::hypot(sp.tx, sp.ty)) * (1.0 + 1e-12) + 1e-6;
     if (hipMemsetAsync(ctx->d_out, 0, 2 * sizeof(double), ctx->stream) != hipSuccess) return bail("hipMemset failed");
     const int nrad = 512, nang = 4096;

@@ -84,6 +84,7 @@ struct svsdf_ctx {
   bool poly_lds = false;             // Polygon: k_solve / k_round run their kPolygonLds variants (edges at the start of LDS)
   unsigned char *d_poly = nullptr;   // Polygon: one device blob [PolyAccel | edges | cell records | slab records | long lists]
   std::vector<double> poly_xy;       // Polygon: the outline as given (host copy)
+  std::vector<int> poly_loops;       // Polygon: vertices per closed loop (empty: one loop)
   std::string err;
 
   // points: this rank's shard, Morton-sorted, split into nbatch contiguous batches

@@ -200,6 +200,36 @@ int svsdf_mesh_outline(const double *V, size_t nv, const int *F, size_t nf, doub
   if (!svsdf_host::mesh_outline(V, nv, F, nf, z0, xy, loops)) return fail(nullptr, SVSDF_ERR_INVALID, "svsdf_mesh_outline: no closed cross-section at z0");
   return outline_out(xy, xy_out, capacity_verts, count);
 }
+static int section_out(const std::vector<double> &xy, const std::vector<int> &sizes, double *xy_out, size_t capacity_verts,
+                       size_t *n_verts, int *loop_sizes, size_t capacity_loops, size_t *n_loops) {
+  *n_verts = xy.size() / 2;
+  *n_loops = sizes.size();
+  if ((xy_out == nullptr) != (loop_sizes == nullptr)) return SVSDF_ERR_INVALID;
+  if (xy_out) {
+    if (capacity_verts < *n_verts || capacity_loops < *n_loops) return SVSDF_ERR_INVALID;
+    std::copy(xy.begin(), xy.end(), xy_out);
+    std::copy(sizes.begin(), sizes.end(), loop_sizes);
+  }
+  return SVSDF_OK;
+}
+int svsdf_mesh_section(const double *V, size_t nv, const int *F, size_t nf, double z0, double *xy_out, size_t capacity_verts,
+                       size_t *n_verts, int *loop_sizes, size_t capacity_loops, size_t *n_loops) {
+  if (!V || !F || !n_verts || !n_loops || !std::isfinite(z0)) return SVSDF_ERR_INVALID;
+  std::vector<double> xy;
+  std::vector<int> sizes;
+  if (!svsdf_host::mesh_section(V, nv, F, nf, z0, xy, sizes)) return fail(nullptr, SVSDF_ERR_INVALID, "svsdf_mesh_section: no closed cross-section at z0");
+  return section_out(xy, sizes, xy_out, capacity_verts, n_verts, loop_sizes, capacity_loops, n_loops);
+}
+int svsdf_mesh_section_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *n_verts,
+                           int *loop_sizes, size_t capacity_loops, size_t *n_loops) {
+  if (!obj_path || !n_verts || !n_loops || !std::isfinite(z0)) return SVSDF_ERR_INVALID;
+  std::vector<double> V, xy;
+  std::vector<int> F, sizes;
+  if (!svsdf_host::read_obj(obj_path, V, F)) return fail(nullptr, SVSDF_ERR_INVALID, std::string("svsdf_mesh_section_obj: cannot read ") + obj_path);
+  if (!svsdf_host::mesh_section(V.data(), V.size() / 3, F.data(), F.size() / 3, z0, xy, sizes))
+    return fail(nullptr, SVSDF_ERR_INVALID, "svsdf_mesh_section_obj: no closed cross-section at z0");
+  return section_out(xy, sizes, xy_out, capacity_verts, n_verts, loop_sizes, capacity_loops, n_loops);
+}
 int svsdf_mesh_outline_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *count,
                            int *loops) {
   if (!obj_path || !count || !std::isfinite(z0)) return SVSDF_ERR_INVALID;
@@ -270,6 +300,8 @@ int svsdf_swept_outline(svsdf_ctx *ctx, int N, const double *coeffs, const doubl
   c.n_devices = 0; c.rank = 0; c.world_size = 1; c.combine = SVSDF_COMBINE_AUTO; c.device = base->device;
   c.polygon_xy = base->poly_xy.empty() ? nullptr : base->poly_xy.data();
   c.polygon_nverts = (int)(base->poly_xy.size() / 2);
+  c.polygon_loop_sizes = base->poly_loops.empty() ? nullptr : base->poly_loops.data();
+  c.polygon_nloops = (int)base->poly_loops.size();
   svsdf_ctx *tmp = svsdf_create(&c);
   if (!tmp) return fail(ctx, SVSDF_ERR_INVALID, std::string("svsdf_swept_outline: ") + svsdf_last_error_string(nullptr));
   std::vector<double> xyz, sdf;

@@ -282,6 +282,7 @@ svsdf_ctx *create_group(const svsdf_config *cfg, int ndev) {
   svsdf_ctx *g = new svsdf_ctx();
   g->cfg = *cfg;
   g->cfg.polygon_xy = nullptr;
+  g->cfg.polygon_loop_sizes = nullptr;
   g->device = cfg->devices[0];
   g->combine = cfg->combine == SVSDF_COMBINE_RCCL ? SVSDF_COMBINE_RCCL : SVSDF_COMBINE_HOST;
   if (const char *e = std::getenv("SVSDF_COMBINE")) g->combine = (std::string(e) == "rccl") ? SVSDF_COMBINE_RCCL : SVSDF_COMBINE_HOST;

@@ -2473,13 +2473,42 @@ k_reduce(const TrajDev *__restrict__ trg, const double *__restrict__ px_, const 
   const int nblocks = (int)gridDim.x;
   double *sums = asm_lds + traj_lds_doubles(N);   // (the accumulator rows are free again: plen <= 4 plen doubles)
   const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
-  for (int e = wv; e < plen; e += kBlock / 64) {
-    double s = 0.0;
-    // (other blocks wrote these: read at device scope, past this CU's vector cache)
-    for (int b = lane; b < nblocks; b += 64) s += __hip_atomic_load(&block_partials[(size_t)e * nblocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (other blocks wrote the partials: read at device scope, past this CU's vector cache)
+  auto part = [&](int e, int b) { return __hip_atomic_load(&block_partials[(size_t)e * nblocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  if (nblocks <= 4) {
+    // Up to 1024 points (the reference's own scale): one THREAD per entry.  k_final's wave leaves in lane 0, for lane
+    // values p_b = 0.0 + partial[e][b] (b < nblocks, zero beyond), the tree ((p0 + p2) + (p1 + p3)) -- the xor steps 32 .. 4
+    // only add zeros to lanes 0 .. 3 -- so the same bits come from four independent loads per thread instead of a dependent
+    // load + butterfly per entry, one entry after the other (that loop cost 60 us of a 480 us callback at 101 points).
+    for (int e = threadIdx.x; e < plen; e += blockDim.x) {
+      double p[4];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (lane == 0) sums[e] = s;
+      for (int b = 0; b < 4; ++b) p[b] = (b < nblocks) ? 0.0 + part(e, b) : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[0] += 0.0; p[1] += 0.0; p[2] += 0.0; p[3] += 0.0; }   // xor 32, 16, 8, 4: the partners hold zeros
+      sums[e] = (p[0] + p[2]) + (p[1] + p[3]);                                             // xor 2, then xor 1
+    }
+  } else {
+    // one wave per entry as in k_final, eight entries in flight per wave (independent loads, interleaved butterflies)
+    constexpr int UN = 8;
+    for (int e0 = wv * UN; e0 < plen; e0 += (kBlock / 64) * UN) {
+      double s[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        s[u] = 0.0;
+        if (e0 + u < plen)
+          for (int b = lane; b < nblocks; b += 64) s[u] += part(e0 + u, b);
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) s[u] += __shfl_xor(s[u], m, 64);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) if (e0 + u < plen) sums[e0 + u] = s[u];
+      }
+    }
   }
   __syncthreads();
   finish_body(sums, N, out, ctl, nbatch, it_end, nonfinite, reinterpret_cast<unsigned long long *>(out + out_partial));

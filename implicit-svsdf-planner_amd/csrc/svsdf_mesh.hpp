@@ -8,13 +8,16 @@
 // svsdf_config::polygon_xy takes: every triangle that straddles the plane contributes the segment between its two
 // crossed edges; crossing points are keyed by the (undirected) mesh edge they lie on, so neighbouring triangles share
 // them exactly and the segments chain into closed loops without any tolerance.  A vertex exactly on the plane counts
-// as above it.  The loop enclosing the largest area is returned (a closed, orientable mesh of one solid gives exactly
-// one loop; callers that plan with the outline must check `loops == 1`, see svsdf_traj_optimizer.hpp).
+// as above it.  mesh_section returns every closed loop, largest |area| first (round 5: a section with a hole or of several
+// solids is planned with all of them -- Polygon::getonlySDF is a minimum / a crossing count over edges, it does not care
+// how they are chained, svsdf_polygon.hpp); mesh_outline the first of them (a closed, orientable mesh of one solid gives
+// exactly one loop).
 #pragma once
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <utility>
@@ -55,13 +58,13 @@ inline bool read_obj(const char *path, std::vector<double> &V, std::vector<int> 
   return !V.empty() && !F.empty();
 }
 
-// Outline of the cross-section z = z0 of the mesh (V: nv x 3, F: nf x 3 vertex indices).  xy_out: interleaved vertices
-// of the closed loop with the largest |area|, in chaining order; loops_out (may be null): number of closed loops found.
+// Cross-section z = z0 of the mesh (V: nv x 3, F: nf x 3 vertex indices): all its closed loops, ordered by decreasing
+// |enclosed area|; xy_out: interleaved vertices, loop after loop, each in chaining order; sizes_out: vertices per loop.
 // Returns false on a malformed mesh (index out of range) or when no triangle straddles the plane.
-inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, double z0, std::vector<double> &xy_out,
-                         int *loops_out) {
+inline bool mesh_section(const double *V, size_t nv, const int *F, size_t nf, double z0, std::vector<double> &xy_out,
+                         std::vector<int> &sizes_out) {
   xy_out.clear();
-  if (loops_out) *loops_out = 0;
+  sizes_out.clear();
   typedef std::pair<int, int> Key;
   std::map<Key, int> id;             // mesh edge -> crossing point
   std::vector<double> px, py;
@@ -100,9 +103,8 @@ inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, do
   const int np = (int)px.size();
   if (np < 3) return false;
   std::vector<char> seen(np, 0);
-  std::vector<int> best;
-  double best_area = -1.0;
-  int loops = 0;
+  std::vector<std::vector<int>> loops;
+  std::vector<double> areas;
   for (int s = 0; s < np; ++s) {
     if (seen[s]) continue;
     std::vector<int> loop;
@@ -118,20 +120,36 @@ inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, do
       if (cur == s) { closed = true; break; }
     }
     if (closed && loop.size() >= 3) {
-      ++loops;
       double a2 = 0.0;   // twice the signed area (shoelace)
       for (size_t q = 0; q < loop.size(); ++q) {
         const int u = loop[q], w = loop[(q + 1) % loop.size()];
         a2 += px[u] * py[w] - px[w] * py[u];
       }
-      // (a finely tessellated small part must not win over a coarse large one: by area, not by vertex count)
-      if (std::fabs(a2) > best_area) { best_area = std::fabs(a2); best.swap(loop); }
+      loops.push_back(std::move(loop));
+      areas.push_back(std::fabs(a2));
     }
   }
-  if (loops_out) *loops_out = loops;
-  if (best.empty()) return false;
-  xy_out.reserve(2 * best.size());
-  for (int i : best) { xy_out.push_back(px[i]); xy_out.push_back(py[i]); }
+  if (loops.empty()) return false;
+  // (a finely tessellated small part must not come before a coarse large one: by area, not by vertex count; ties keep the
+  // order in which the loops were found, which is the order of the mesh's faces)
+  std::vector<size_t> order(loops.size());
+  for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return areas[a] > areas[b]; });
+  for (size_t k : order) {
+    for (int i : loops[k]) { xy_out.push_back(px[i]); xy_out.push_back(py[i]); }
+    sizes_out.push_back((int)loops[k].size());
+  }
+  return true;
+}
+
+// The loop enclosing the largest area (xy_out) and the number of closed loops of the section (loops_out, may be null).
+inline bool mesh_outline(const double *V, size_t nv, const int *F, size_t nf, double z0, std::vector<double> &xy_out,
+                         int *loops_out) {
+  std::vector<int> sizes;
+  if (loops_out) *loops_out = 0;
+  if (!mesh_section(V, nv, F, nf, z0, xy_out, sizes)) { xy_out.clear(); return false; }
+  if (loops_out) *loops_out = (int)sizes.size();
+  xy_out.resize(2 * (size_t)sizes[0]);
   return true;
 }
 

@@ -8,16 +8,14 @@
 //
 //   distance  three uniform grids in the body frame: a fine one around the outline, a coarse one out to ~3 shape sizes,
 //             a far one out to 40 (beyond that: all edges).  A cell lists, in ascending edge order, every edge that can
-//             be the nearest one for SOME point of the (slightly enlarged) cell.  First pass (fine, coarse):  lb_e <= U,
-//             lb_e = exact distance cell <-> edge,  U = min over edges of the largest corner-to-edge distance (distance
-//             to a segment is convex, so that is its maximum over the cell).  Second pass (and the only one of the far
-//             grid, run down a pyramid of grids): sample points, each standing for a sub-rectangle of half diagonal rho;
-//             with e* the nearest edge at the sample c, an edge e stays iff  d(c, e) - d(c, e*) <= lip rho,  lip =
-//             min(2, diam(e u e*) / (d(c, e*) - rho)) bounding |grad (d_e - d_e*)| = the difference of the two unit
-//             directions: far from a rounded corner its short edges are all nearly equidistant but their bisectors fan
-//             out.  An edge that is not listed is farther than the nearest listed one by a margin (1e-9) far above the
-//             rounding of the per-edge arithmetic, so the minimum over the listed edges is the minimum over all edges:
-//             the same double the reference's loop ends with.
+//             be the nearest one for SOME point of the (slightly enlarged) cell.  The lists come down a pyramid of grids
+//             (16, 32, .. cells per side; one more halving below the fine and the coarse level, united per cell): a cell
+//             filters its parent's list with one sample, its centre c (half diagonal rho): with e* the nearest edge at c,
+//             an edge e stays iff  d(c, e) - d(c, e*) <= lip rho,  lip = min(2, diam(e u e*) / (d(c, e*) - rho)) bounding
+//             |grad (d_e - d_e*)| = the difference of the two unit directions: far from a rounded corner its short edges
+//             are all nearly equidistant but their bisectors fan out.  An edge that is not listed is farther than the
+//             nearest listed one by a margin (1e-9) far above the rounding of the per-edge arithmetic, so the minimum
+//             over the listed edges is the minimum over all edges: the same double the reference's loop ends with.
 //   parity    a cell that stays clear of the outline knows the parity of the crossing count of all its queries (the
 //             reference's test only depends on rounding within ~1e-15 of an edge); a cell the outline passes through
 //             carries its own crossing candidates in the upper half of its record (plus the parity of the edges that
@@ -35,11 +33,20 @@
 // than its record, an operand outside poly_quot's range, a crossing angle within 1e-9 rad of 0 or pi, a query outside
 // all grids) re-evaluates on its own with the division and the reference's atan2 formula.
 // __host__ __device__: tests/cpp/poly_host.cpp runs the very same functions on the CPU against the oracle's plain loop.
+//
+// Outlines of several closed loops (round 5; a section with a hole, two solids -- BASELINE config 5 says "arbitrary .obj
+// mesh").  Polygon::getonlySDF is a minimum over edges and a crossing count over edges: it does not care how the edges are
+// chained.  The edge array holds the loops one after the other, each CLOSED BY A COPY OF ITS FIRST VERTEX whose own edge
+// (it would run on to the next loop) is dead: a zero-length edge, v = 0, vv = 0.  Every real edge i still ends at entry
+// i + 1, a zero-length edge can neither win the distance (the reference's 0 / 0 = NaN never passes `dis < dis_min`) nor
+// count as a crossing (theta_s == theta_e), and it is kept out of every candidate list -- so the device code is the
+// single-loop code, unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 namespace svsdf {
@@ -85,10 +92,10 @@ struct PolyAccel {
 };
 
 #ifndef SVSDF_POLY_REFINE
-#define SVSDF_POLY_REFINE 2   // sample points per cell side in the second pass of the candidate lists (0 = off)
+#define SVSDF_POLY_REFINE 2   // fine / coarse level: cells per side of the sub-grid whose lists a cell unites (1: none, 2, 4)
 #endif
 constexpr int kPolyGrid = 256;        // cells per side of every grid level (poly_locate)
-constexpr int kPolyMaxVerts = 4096;   // = SVSDF_MAX_POLY_VERTS (16-bit edge indices; host build time)
+constexpr int kPolyMaxVerts = 8190;   // = SVSDF_MAX_POLY_VERTS: entries of the edge array incl. the loops' closing copies (list counts are 13 bits)
 
 // true when the condition holds in any lane of the wave (the host build has one lane)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -343,10 +350,11 @@ struct PolyAccelHost {
 };
 
 namespace poly_detail {
-struct Seg { double sx, sy, ex, ey, vx, vy, vv; };
+struct Seg { double sx, sy, ex, ey, vx, vy, vv, rvv; };   // rvv = 1 / vv (0 for a zero-length edge)
+// (list building only: every use carries 1e-9 margins, so the product with the reciprocal stands in for the division)
 inline double seg_point_dist(const Seg &e, double x, double y) {
   const double wx = x - e.sx, wy = y - e.sy;
-  double t = (e.vv > 0.0) ? (wx * e.vx + wy * e.vy) / e.vv : 0.0;
+  double t = (wx * e.vx + wy * e.vy) * e.rvv;
   t = std::min(1.0, std::max(0.0, t));
   const double dx = x - (e.sx + t * e.vx), dy = y - (e.sy + t * e.vy);
   return std::sqrt(dx * dx + dy * dy);
@@ -397,11 +405,36 @@ inline PolyRec pack_list(const std::vector<unsigned short> &list, std::vector<un
 }
 }  // namespace poly_detail
 
-// returns false when the outline cannot be handled (n out of range, non-finite vertex)
-inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng_fine = 128, int ng_coarse = 256,
-                             int nslab = 256, int refine = SVSDF_POLY_REFINE, int nxb = 32) {
+// returns false when the outline cannot be handled (n out of range, non-finite vertex, loop sizes that do not add up)
+// loop_sizes / nloops: the vertex list is nloops closed loops one after the other (null / < 2: one loop, the reference's
+// chain).  ng_fine / ng_coarse are rounded up to a power of two in [16, 256].
+inline bool build_poly_accel(const double *xy_in, int n_in, PolyAccelHost &out, int ng_fine = 128, int ng_coarse = 256,
+                             int nslab = 256, int refine = SVSDF_POLY_REFINE, int nxb = 32, const int *loop_sizes = nullptr,
+                             int nloops = 0) {
   using namespace poly_detail;
-  if (n < 3 || n > kPolyMaxVerts) return false;
+  if (n_in < 3) return false;
+  // entries of the edge array: the vertices, plus -- for an outline of several loops -- a copy of each loop's first vertex
+  // behind its last one, flagged dead (see the header comment)
+  std::vector<double> xy_e;
+  std::vector<char> dead;
+  const double *xy = xy_in;
+  int n = n_in;
+  if (loop_sizes && nloops >= 2) {
+    long long tot = 0;
+    for (int k = 0; k < nloops; ++k) { if (loop_sizes[k] < 3) return false; tot += loop_sizes[k]; }
+    if (tot != n_in) return false;
+    int b = 0;
+    for (int k = 0; k < nloops; ++k) {
+      for (int i = 0; i < loop_sizes[k]; ++i) { xy_e.push_back(xy_in[2 * (b + i)]); xy_e.push_back(xy_in[2 * (b + i) + 1]); dead.push_back(0); }
+      xy_e.push_back(xy_in[2 * b]); xy_e.push_back(xy_in[2 * b + 1]); dead.push_back(1);
+      b += loop_sizes[k];
+    }
+    xy = xy_e.data();
+    n = (int)dead.size();
+  } else {
+    dead.assign((size_t)n, 0);
+  }
+  if (n > kPolyMaxVerts) return false;
   out = PolyAccelHost{};
   out.edges.resize(n);
   std::vector<Seg> seg(n);
@@ -411,9 +444,11 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     const int j = (i + 1 == n) ? 0 : i + 1;
     Seg &e = seg[i];
     e.sx = xy[2 * i]; e.sy = xy[2 * i + 1]; e.ex = xy[2 * j]; e.ey = xy[2 * j + 1];
+    if (dead[i]) { e.ex = e.sx; e.ey = e.sy; }    // the closing copy of a loop's first vertex: no edge leaves it
     if (!std::isfinite(e.sx) || !std::isfinite(e.sy)) return false;
     e.vx = e.ex - e.sx; e.vy = e.ey - e.sy;       // Eigen::Vector2d v = end - start
     e.vv = e.vx * e.vx + e.vy * e.vy;             // v.squaredNorm()
+    e.rvv = (e.vv > 0.0) ? 1.0 / e.vv : 0.0;
     out.edges[i] = PolyEdge{e.sx, e.sy, e.vx, e.vy, e.vv, (e.vv > 0.0) ? 1.0 / e.vv : 0.0};
     if (e.vv > 0.0 && !(e.vv >= 1e-100 && e.vv <= 1e100)) div_ok = 0;
     xmin = std::min(xmin, e.sx); xmax = std::max(xmax, e.sx);
@@ -429,20 +464,144 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
   const int ngs[2] = {ng_fine, ng_coarse};
   const double grow = 1e-7 * scale;   // every cell is enlarged by this on all sides: a query whose cell index is decided
                                       // by the last bit of (x - x0) * inv_h is still covered by the neighbour's list
-  std::vector<double> ub(n), row[2];
   std::vector<unsigned short> list, plist;
   std::vector<char> clear_of_outline;   // per cell: no edge within 1e-6 scale of it
-  std::vector<char> keep;
-  std::vector<double> dsub;
+  const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  // Candidate lists of a square grid of G x G cells (origin (gx0, gy0), cell size hc; G = 16 * 2^k), by descent through a
+  // pyramid of grids (16, 32, .. G cells per side, then `sub` further halvings whose cells are united into the leaf they
+  // tile).  A cell filters its parent's list with one sample, its centre c (rho = half diagonal of the cell enlarged by
+  // `grow`): with e* the nearest listed edge at c, g(p) = d(p, e) - d(p, e*) has |grad g| = |u_e - u_e*| (unit vectors
+  // from the closest points a, b to p) <= 2 |a - b| / (d(p, e) + d(p, e*)) <= diam(e u e*) / (d(c, e*) - rho) =: lip (and
+  // <= 2 always: both distances are 1-Lipschitz), so g(c) > lip rho means e* is nearer than e in the whole cell: e is the
+  // nearest edge nowhere in it.  Every filter is valid for its whole cell, which contains the final cell; an edge that
+  // is dropped is farther than a listed one by the 1e-9 margins, far above the rounding of the per-edge arithmetic.  Far
+  // from a rounded corner all of its short edges are nearly equidistant (a bound on the distances alone keeps them all),
+  // but their bisectors fan out and lip is small there.
+  // Round 5: all three levels are built this way.  Rounds 3-4 built the fine and the coarse level cell by cell from the
+  // distances of the cell's corner nodes to EVERY edge (first pass) and refined each list with 2 x 2 samples: 0.45 / 0.67 s
+  // of svsdf_create for outlines of 614 / 754 vertices, almost all of it in first-pass lists of ~ 100 edges per cell that
+  // the refinement then cut to ~ 5; the descent never holds more than a parent's (short) list.
+  // (lists are kept flat per level -- start offsets + one array of edge indices: a vector per cell made the descent an
+  // exercise in malloc)
+  struct FlatLists {
+    std::vector<unsigned> start;        // cells + 1 offsets into `idx`
+    std::vector<unsigned short> idx;
+    const unsigned short *list(size_t c) const { return idx.data() + start[c]; }
+    size_t size(size_t c) const { return start[c + 1] - start[c]; }
+  };
+  auto pyramid = [&](double gx0, double gy0, double hc_leaf, int G, int sub, FlatLists &leaf) {
+    FlatLists cur, nxt;
+    cur.start = {0u, 0u};
+    for (int i = 0; i < n; ++i) if (seg[i].vv > 0.0) cur.idx.push_back((unsigned short)i);
+    cur.start[1] = (unsigned)cur.idx.size();
+    auto sq = [](double x, double y) { return x * x + y * y; };
+    const int Gs = G << sub;
+    const double ext_ = hc_leaf * G;
+    for (int g = 1; g < Gs;) {
+      const int g2 = (g == 1) ? std::min(16, Gs) : 2 * g, ratio = g2 / g;
+      const double hc = ext_ / g2;
+      // (a cell below the leaf level stands for its part of the ENLARGED leaf: enlarged by grow as well)
+      const double rho = 0.5 * std::sqrt(2.0) * (hc + 2.0 * grow) * (1.0 + 1e-9);
+      // rows are independent (a cell reads its parent's list and writes its own): large levels are split over a few host
+      // threads, every cell computed exactly as in the serial loop, the threads' pieces concatenated in row order
+      const int nthr = std::max(1, std::min(nthreads, g2 / 2));
+      std::vector<std::vector<unsigned short>> tdata(nthr);
+      std::vector<std::vector<unsigned>> tcount(nthr);
+      auto rows = [&](int t, int y0, int y1) {
+        std::vector<double> dsub;
+        std::vector<unsigned short> &data = tdata[t];
+        std::vector<unsigned> &cnt = tcount[t];
+        cnt.reserve((size_t)(y1 - y0) * g2);
+        for (int iy = y0; iy < y1; ++iy)
+          for (int ix = 0; ix < g2; ++ix) {
+            const size_t pc = (size_t)(iy / ratio) * g + ix / ratio;
+            const unsigned short *par = cur.list(pc);
+            const size_t m = cur.size(pc);
+            const size_t before = data.size();
+            // (below the leaf level a list of one or two edges is not worth another sample: the children keep it)
+            if (g2 > G && m <= 2) { data.insert(data.end(), par, par + m); }
+            else if (m > 0) {
+              const double px = gx0 + (ix + 0.5) * hc, py = gy0 + (iy + 0.5) * hc;
+              dsub.resize(m);
+              double dmin = 1e300;
+              size_t kmin = 0;
+              for (size_t k = 0; k < m; ++k) {
+                dsub[k] = seg_point_dist(seg[par[k]], px, py);
+                if (dsub[k] < dmin) { dmin = dsub[k]; kmin = k; }
+              }
+              const Seg &b = seg[par[kmin]];
+              const double dlow = dmin * (1.0 - 1e-9) - rho - 1e-9 * scale;
+              for (size_t k = 0; k < m; ++k) {
+                // (the two ends of the test need no lip: 0 <= lip <= 2)
+                const double gap = dsub[k] - dmin, slackk = 1e-9 * scale + 1e-9 * dsub[k];
+                if (gap <= slackk) { data.push_back(par[k]); continue; }
+                if (gap > 2.0 * rho * (1.0 + 1e-9) + slackk) continue;
+                double lip = 2.0;
+                if (dlow > 0.0) {
+                  const Seg &e = seg[par[k]];
+                  const double diam = std::sqrt(std::max(std::max(sq(e.sx - b.sx, e.sy - b.sy), sq(e.sx - b.ex, e.sy - b.ey)),
+                                                         std::max(sq(e.ex - b.sx, e.ey - b.sy), sq(e.ex - b.ex, e.ey - b.ey))));
+                  lip = std::min(2.0, diam * (1.0 + 1e-9) / dlow);
+                }
+                if (gap <= lip * rho * (1.0 + 1e-9) + slackk) data.push_back(par[k]);
+              }
+            }
+            cnt.push_back((unsigned)(data.size() - before));
+          }
+      };
+      if (nthr == 1) rows(0, 0, g2);
+      else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t) pool.emplace_back(rows, t, (int)((long long)g2 * t / nthr), (int)((long long)g2 * (t + 1) / nthr));
+        for (std::thread &t : pool) t.join();
+      }
+      nxt.start.assign(1, 0u);
+      nxt.start.reserve((size_t)g2 * g2 + 1);
+      nxt.idx.clear();
+      for (int t = 0; t < nthr; ++t) {
+        for (unsigned c : tcount[t]) nxt.start.push_back(nxt.start.back() + c);
+        nxt.idx.insert(nxt.idx.end(), tdata[t].begin(), tdata[t].end());
+      }
+      std::swap(cur, nxt);
+      g = g2;
+    }
+    if (sub == 0) { std::swap(leaf, cur); return; }
+    // a leaf's list = the union of the lists of the (1 << sub)^2 cells that tile it (ascending, no duplicates)
+    const int r = 1 << sub;
+    leaf.start.assign(1, 0u);
+    leaf.start.reserve((size_t)G * G + 1);
+    leaf.idx.clear();
+    std::vector<unsigned short> acc, tmp;
+    for (int iy = 0; iy < G; ++iy)
+      for (int ix = 0; ix < G; ++ix) {
+        acc.clear();
+        for (int jy = 0; jy < r; ++jy)
+          for (int jx = 0; jx < r; ++jx) {
+            const size_t c = (size_t)(iy * r + jy) * Gs + (ix * r + jx);
+            const unsigned short *l0 = cur.list(c);
+            const size_t m = cur.size(c);
+            tmp.resize(acc.size() + m);
+            tmp.resize((size_t)(std::set_union(acc.begin(), acc.end(), l0, l0 + m, tmp.begin()) - tmp.begin()));
+            acc.swap(tmp);
+          }
+        leaf.idx.insert(leaf.idx.end(), acc.begin(), acc.end());
+        leaf.start.push_back((unsigned)leaf.idx.size());
+      }
+  };
+  // ---- fine (around the outline) and coarse (to ~3 shape sizes) levels
+  FlatLists lists;
   for (int l = 0; l < 2; ++l) {
     PolyLevel &lv = h.lv[l];
     const double m = margins[l];
     const double ext = L + 2.0 * m;
     // every level is 256 x 256 records around the common centre (poly_locate: one index formula); the fine level
     // only fills the central ngs[0] x ngs[0] block of it, the cells its extent covers -- the rest is never looked up
-    // (nfill even: the filled block must sit symmetrically about the common centre, poly_locate picks the level by the
-    // symmetric radius lr[l] -- an odd value left a half-cell strip of empty records inside it)
-    const int ng = kPolyGrid, nfill = std::min(kPolyGrid, std::max(2, ngs[l] + (ngs[l] & 1))), lo = (ng - nfill) / 2, hi = lo + nfill;
+    // (a power of two >= 16: the pyramid halves it down; even: the filled block must sit symmetrically about the common
+    // centre, poly_locate picks the level by the symmetric radius lr[l])
+    const int ng = kPolyGrid;
+    int nfill = 16;
+    while (nfill < ngs[l] && nfill < kPolyGrid) nfill *= 2;
+    const int lo = (ng - nfill) / 2, hi = lo + nfill;
     const double hcell = ext / nfill;
     lv.x0 = 0.5 * (xmin + xmax) - 0.5 * ng * hcell;
     lv.y0 = 0.5 * (ymin + ymax) - 0.5 * ng * hcell;
@@ -450,111 +609,31 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     lv.nx = ng; lv.ny = ng;
     lv.base = (unsigned)out.cells.size();
     lv.pad = 0;
-    // distances grid node -> edge, one node row at a time (a node is a corner of up to four cells)
-    auto fill_row = [&](std::vector<double> &r, int iy) {
-      r.resize((size_t)(ng + 1) * n);
-      const double y = lv.y0 + iy * hcell;
-      for (int ix = 0; ix <= ng; ++ix) {
-        const double x = lv.x0 + ix * hcell;
-        for (int i = 0; i < n; ++i) r[(size_t)ix * n + i] = seg_point_dist(seg[i], x, y);
-      }
-    };
-    fill_row(row[lo & 1], lo);
-    const double diam = 1.4143 * (hcell + 2.0 * grow);
-    for (int iy = 0; iy < ng; ++iy) {
-      if (iy < lo || iy >= hi) {
-        out.cells.resize(out.cells.size() + ng, PolyRec{{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}});
-        clear_of_outline.resize(clear_of_outline.size() + ng, 2);   // 2: not a cell of this level
-        continue;
-      }
-      fill_row(row[(iy + 1) & 1], iy + 1);
-      const std::vector<double> &r0 = row[iy & 1], &r1 = row[(iy + 1) & 1];
+    pyramid(lv.x0 + lo * hcell, lv.y0 + lo * hcell, hcell, nfill, (refine >= 4) ? 2 : (refine >= 2) ? 1 : 0, lists);
+    for (int iy = 0; iy < ng; ++iy)
       for (int ix = 0; ix < ng; ++ix) {
-        if (ix < lo || ix >= hi) {
+        if (iy < lo || iy >= hi || ix < lo || ix >= hi) {
           out.cells.push_back(PolyRec{{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}});
-          clear_of_outline.push_back(2);
+          clear_of_outline.push_back(2);   // 2: not a cell of this level
           continue;
         }
+        const size_t lc = (size_t)(iy - lo) * nfill + (ix - lo);
+        list.assign(lists.list(lc), lists.list(lc) + lists.size(lc));
+        const std::vector<unsigned short> &lst = list;
+        // distance of the enlarged cell to the outline = to the nearest of its listed edges (the nearest edge of any of
+        // its points is listed)
         const double cx0 = lv.x0 + ix * hcell - grow, cx1 = lv.x0 + (ix + 1) * hcell + grow;
         const double cy0 = lv.y0 + iy * hcell - grow, cy1 = lv.y0 + (iy + 1) * hcell + grow;
-        // U >= the nearest-edge distance of every point of the enlarged cell: the distance to a segment is convex
-        // (maximum over the cell at a corner) and 1-Lipschitz (the enlarged corners are within 1.4143 grow of the nodes)
-        double U = 1e300;
-        for (int i = 0; i < n; ++i) {
-          const double dmax = std::max(std::max(r0[(size_t)ix * n + i], r0[(size_t)(ix + 1) * n + i]),
-                                       std::max(r1[(size_t)ix * n + i], r1[(size_t)(ix + 1) * n + i])) + 1.4143 * grow;
-          // (a zero-length edge -- repeated vertex -- never wins the reference's `dis < dis_min`: 0/0 gives NaN)
-          ub[i] = (seg[i].vv > 0.0) ? dmax : 1e300;
-          U = std::min(U, ub[i]);
-        }
-        const double thr = U * (1.0 + 1e-9) + 1e-9 * scale;
-        list.clear();
-        double dcell = 1e300;   // distance of the enlarged cell to the outline
-        for (int i = 0; i < n; ++i) {
-          if (ub[i] - diam > thr) continue;   // cheap reject (1-Lipschitz): every point of the cell is farther than thr
-          const double dr = rect_seg_dist(seg[i], cx0, cy0, cx1, cy1);
-          if (dr <= thr) { list.push_back((unsigned short)i); dcell = std::min(dcell, dr); }
-        }
+        double dcell = 1e300;
+        for (unsigned short i : lst) dcell = std::min(dcell, rect_seg_dist(seg[i], cx0, cy0, cx1, cy1));
         clear_of_outline.push_back(dcell > 1e-6 * scale ? 1 : 0);
-        // Second pass over the cell's own list, refine x refine sample points c, each standing for the sub-rectangle
-        // around it (half diagonal rho; the sub-rectangles tile the enlarged cell).  With e* the nearest listed edge at
-        // c, g(p) = d(p, e) - d(p, e*) has |grad g| = |u_e - u_e*| (unit vectors from the closest points a, b to p)
-        // <= 2 |a - b| / (d(p, e) + d(p, e*)) <= diam(e u e*) / (dmin(c) - rho) =: lip (and <= 2 always), so
-        // g(c) > lip * rho means e* is nearer than e in the whole sub-rectangle: e is the nearest edge nowhere in it.
-        // Kept = the union over the sub-rectangles of the edges that pass.  Far from a rounded corner all of its short
-        // edges are nearly equidistant (a bound on the distances alone keeps them all), but their bisectors fan out
-        // and lip is small there.
-        if (refine > 0 && list.size() > 1) {
-          const size_t m = list.size();
-          keep.assign(m, 0);
-          size_t nkept = 0;
-          const double sx = (cx1 - cx0) / refine, sy = (cy1 - cy0) / refine;
-          const double rho = 0.5 * std::sqrt(sx * sx + sy * sy) * (1.0 + 1e-9);
-          dsub.resize(m);
-          for (int jy = 0; jy < refine && nkept < m; ++jy)
-            for (int jx = 0; jx < refine && nkept < m; ++jx) {
-              const double px = cx0 + (jx + 0.5) * sx, py = cy0 + (jy + 0.5) * sy;
-              double dmin = 1e300;
-              size_t kmin = 0;
-              for (size_t k = 0; k < m; ++k) {
-                const Seg &e = seg[list[k]];
-                dsub[k] = (e.vv > 0.0) ? seg_point_dist(e, px, py) : 1e300;
-                if (dsub[k] < dmin) { dmin = dsub[k]; kmin = k; }
-              }
-              const Seg &b = seg[list[kmin]];
-              const double dlow = dmin * (1.0 - 1e-9) - rho - 1e-9 * scale;
-              for (size_t k = 0; k < m; ++k) {
-                if (keep[k]) continue;
-                double lip = 2.0;
-                if (dlow > 0.0) {
-                  const Seg &e = seg[list[k]];
-                  auto sq = [](double x, double y) { return x * x + y * y; };
-                  const double diam = std::sqrt(std::max(std::max(sq(e.sx - b.sx, e.sy - b.sy), sq(e.sx - b.ex, e.sy - b.ey)),
-                                                         std::max(sq(e.ex - b.sx, e.ey - b.sy), sq(e.ex - b.ex, e.ey - b.ey))));
-                  lip = std::min(2.0, diam * (1.0 + 1e-9) / dlow);
-                }
-                if (dsub[k] - dmin <= lip * rho * (1.0 + 1e-9) + 1e-9 * scale + 1e-9 * dsub[k]) { keep[k] = 1; ++nkept; }
-              }
-            }
-          if (nkept < m) {
-            size_t o = 0;
-            for (size_t k = 0; k < m; ++k) if (keep[k]) list[o++] = list[k];
-            list.resize(o);
-          }
-        }
-        out.cand_total += list.size();
-        out.cand_max = std::max(out.cand_max, list.size());
-        out.cells.push_back(pack_list(list, out.over));
-
+        out.cand_total += lst.size();
+        out.cand_max = std::max(out.cand_max, lst.size());
+        out.cells.push_back(pack_list(lst, out.over));
       }
-    }
   }
-  // ---- far level: the candidate lists of a 256 x 256 grid out to 40 shape sizes, by descent through a pyramid of grids
-  // (16, 32, .. 256 cells per side).  A cell filters its parent's list with one sample, its centre c (half diagonal rho
-  // of the enlarged cell), by the bisector test of the second pass above: e* the nearest listed edge at c, e stays iff
-  // d(c, e) - d(c, e*) <= min(2, diam(e u e*) / (d(c, e*) - rho)) rho.  Every filter is valid for its whole cell, which
-  // contains the final cell.  (A query this far out used to walk all edges -- and with it the 63 other lanes of its wave:
-  // a tenth of the wave-level evaluations of config 5, 40 % of its vector instructions.)
+  // ---- far level: 256 x 256 cells out to 40 shape sizes.  (A query this far out used to walk all edges -- and with it
+  // the 63 other lanes of its wave: a tenth of the wave-level evaluations of config 5, 40 % of its vector instructions.)
   {
     PolyLevel &lv = h.lv[2];
     const double ext = L + 2.0 * 40.0 * L;
@@ -565,48 +644,13 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     lv.nx = ngf; lv.ny = ngf;
     lv.base = (unsigned)out.cells.size();
     lv.pad = 0;
-    std::vector<std::vector<unsigned short>> cur(1), nxt;
-    for (int i = 0; i < n; ++i) if (seg[i].vv > 0.0) cur[0].push_back((unsigned short)i);
-    auto sq = [](double x, double y) { return x * x + y * y; };
-    for (int g = 1; g < ngf;) {
-      const int g2 = (g == 1) ? 16 : 2 * g, ratio = g2 / g;
-      const double hc = ext / g2;
-      nxt.assign((size_t)g2 * g2, {});
-      const double rho = 0.5 * std::sqrt(2.0) * (hc + 2.0 * grow) * (1.0 + 1e-9);
-      for (int iy = 0; iy < g2; ++iy)
-        for (int ix = 0; ix < g2; ++ix) {
-          const std::vector<unsigned short> &par = cur[(size_t)(iy / ratio) * g + ix / ratio];
-          std::vector<unsigned short> &dst = nxt[(size_t)iy * g2 + ix];
-          const double px = lv.x0 + (ix + 0.5) * hc, py = lv.y0 + (iy + 0.5) * hc;
-          const size_t m = par.size();
-          dsub.resize(m);
-          double dmin = 1e300;
-          size_t kmin = 0;
-          for (size_t k = 0; k < m; ++k) {
-            dsub[k] = seg_point_dist(seg[par[k]], px, py);
-            if (dsub[k] < dmin) { dmin = dsub[k]; kmin = k; }
-          }
-          if (m == 0) continue;
-          const Seg &b = seg[par[kmin]];
-          const double dlow = dmin * (1.0 - 1e-9) - rho - 1e-9 * scale;
-          for (size_t k = 0; k < m; ++k) {
-            double lip = 2.0;
-            if (dlow > 0.0) {
-              const Seg &e = seg[par[k]];
-              const double diam = std::sqrt(std::max(std::max(sq(e.sx - b.sx, e.sy - b.sy), sq(e.sx - b.ex, e.sy - b.ey)),
-                                                     std::max(sq(e.ex - b.sx, e.ey - b.sy), sq(e.ex - b.ex, e.ey - b.ey))));
-              lip = std::min(2.0, diam * (1.0 + 1e-9) / dlow);
-            }
-            if (dsub[k] - dmin <= lip * rho * (1.0 + 1e-9) + 1e-9 * scale + 1e-9 * dsub[k]) dst.push_back(par[k]);
-          }
-        }
-      cur.swap(nxt);
-      g = g2;
-    }
+    pyramid(lv.x0, lv.y0, ext / ngf, ngf, 0, lists);
     const double M = 1e-6 * scale + grow;
     for (int iy = 0; iy < ngf; ++iy)
       for (int ix = 0; ix < ngf; ++ix) {
-        const std::vector<unsigned short> &l2 = cur[(size_t)iy * ngf + ix];
+        const size_t lc = (size_t)iy * ngf + ix;
+        list.assign(lists.list(lc), lists.list(lc) + lists.size(lc));
+        const std::vector<unsigned short> &l2 = list;
         const double hc = ext / ngf;
         const double cx0 = lv.x0 + ix * hc, cx1 = cx0 + hc, cy0 = lv.y0 + iy * hc, cy1 = cy0 + hc;
         // outside the outline's bounding box (by a margin): no ray of the cell meets it, or every edge is to its left
@@ -634,7 +678,9 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
     list.clear();
     for (int i = 0; i < n; ++i) {
       const Seg &e = seg[i];
-      if (std::max(e.sy, e.ey) >= a && std::min(e.sy, e.ey) <= b) list.push_back((unsigned short)i);
+      // (a zero-length edge -- a repeated vertex, a loop's closing copy -- has theta_s == theta_e: it never counts as a crossing,
+      // and listing it would only send its queries down the lane's own path, the cross product being exactly zero)
+      if (e.vv > 0.0 && std::max(e.sy, e.ey) >= a && std::min(e.sy, e.ey) <= b) list.push_back((unsigned short)i);
     }
     out.slab_max = std::max(out.slab_max, list.size());
     // ... split by x: bucket b takes the queries with x >= xmin + b hx (bucket 0 also those left of xmin; up to the
@@ -658,7 +704,15 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
   for (int l = 0; l < 2; ++l) {
     const PolyLevel &lv = h.lv[l];
     const double hcell = 1.0 / lv.inv_h;
-    for (int iy = 0; iy < lv.ny; ++iy)
+    std::vector<int> rowedges;   // edges whose y-range holds the row's centre line: the only ones its centre rays can cross
+    for (int iy = 0; iy < lv.ny; ++iy) {
+      {
+        const double y = lv.y0 + (iy + 0.5) * hcell;
+        rowedges.clear();
+        if (y >= ymin && y <= ymax)
+          for (int i = 0; i < n; ++i)
+            if (seg[i].vv > 0.0 && std::max(seg[i].sy, seg[i].ey) >= y && std::min(seg[i].sy, seg[i].ey) <= y) rowedges.push_back(i);
+      }
       for (int ix = 0; ix < lv.nx; ++ix) {
         const size_t c = (size_t)lv.base + (size_t)iy * lv.nx + ix;
         if (clear_of_outline[c] == 2) continue;
@@ -679,6 +733,7 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
           plist.clear();
           for (int i = 0; i < n; ++i) {
             const Seg &e = seg[i];
+            if (!(e.vv > 0.0)) continue;   // zero-length: never a crossing
             const double ylo = std::min(e.sy, e.ey), yhi = std::max(e.sy, e.ey);
             if (yhi < cy0 || ylo > cy1) continue;
             if (std::max(e.sx, e.ex) < cx0 - 2.0 * h.tol) continue;
@@ -698,12 +753,12 @@ inline bool build_poly_accel(const double *xy, int n, PolyAccelHost &out, int ng
         const double x = lv.x0 + (ix + 0.5) * hcell, y = lv.y0 + (iy + 0.5) * hcell;
         int rs = 0;
         if (y >= ymin && y <= ymax && x <= xmax)
-          for (int i = 0; i < n; ++i)
-            if (std::max(seg[i].sy, seg[i].ey) >= y && std::min(seg[i].sy, seg[i].ey) <= y &&
-                poly_cross_ray(seg[i].sx - x, seg[i].sy - y, seg[i].ex - x, seg[i].ey - y)) rs++;
+          for (int i : rowedges)
+            if (poly_cross_ray(seg[i].sx - x, seg[i].sy - y, seg[i].ex - x, seg[i].ey - y)) rs++;
         out.cells[c].w[7] |= (rs % 2 == 0 ? 1u : 2u) << 30;
         out.cells_known++;
       }
+    }
   }
   h.cx = 0.5 * (xmin + xmax); h.cy = 0.5 * (ymin + ymax);
   for (int l = 0; l < 3; ++l) {

@@ -30,7 +30,7 @@ EXPORTS = [
     "svsdf_set_conditions", "svsdf_sum_partials", "svsdf_shape_bound",
     "svsdf_mesh_outline", "svsdf_mesh_outline_obj", "svsdf_swept_outline", "svsdf_outline_extrude",
     "svsdf_get_plan", "svsdf_set_plan", "svsdf_set_combine", "svsdf_group_info", "svsdf_debug_sdf_at",
-    "svsdf_group_stripe", "svsdf_set_group_serial", "svsdf_shape_selfcheck",
+    "svsdf_group_stripe", "svsdf_set_group_serial", "svsdf_shape_selfcheck", "svsdf_mesh_section", "svsdf_mesh_section_obj",
 ]
 
 
@@ -55,7 +55,8 @@ class Config(C.Structure):
                 ("weight_p", C.c_double), ("rho", C.c_double), ("head_state", C.c_double * 9),
                 ("tail_state", C.c_double * 9), ("device", C.c_int), ("polygon_nverts", C.c_int),
                 ("polygon_xy", _dp), ("rank", C.c_int), ("world_size", C.c_int), ("flags", C.c_int),
-                ("n_devices", C.c_int), ("devices", C.c_int * 8), ("combine", C.c_int)]
+                ("n_devices", C.c_int), ("devices", C.c_int * 8), ("combine", C.c_int),
+                ("polygon_nloops", C.c_int), ("polygon_loop_sizes", C.POINTER(C.c_int))]
 
 
 class Stats(C.Structure):
@@ -227,6 +228,48 @@ def mesh_outline(V, F, z0=0.0):
     return xy, loops.value
 
 
+def mesh_section(V, F, z0=0.0):
+    """All closed loops of the z = z0 section of a triangle mesh (svsdf_mesh_section): (xy (n, 2) loop after loop, largest
+    enclosed area first; loop sizes)."""
+    L = lib()
+    V = _f64(V).reshape(-1, 3)
+    F = np.ascontiguousarray(F, dtype=np.int32).reshape(-1, 3)
+    n, nl = C.c_size_t(), C.c_size_t()
+    ip = C.POINTER(C.c_int)
+    L.svsdf_mesh_section.argtypes = [_dp, C.c_size_t, ip, C.c_size_t, C.c_double, _dp, C.c_size_t, C.POINTER(C.c_size_t), ip,
+                                     C.c_size_t, C.POINTER(C.c_size_t)]
+    rc = L.svsdf_mesh_section(_p(V), len(V), F.ctypes.data_as(ip), len(F), float(z0), None, 0, C.byref(n), None, 0, C.byref(nl))
+    if rc:
+        raise SvsdfError("svsdf_mesh_section failed: " + L.svsdf_last_error_string(None).decode())
+    xy = np.zeros((n.value, 2))
+    sizes = np.zeros(nl.value, dtype=np.int32)
+    rc = L.svsdf_mesh_section(_p(V), len(V), F.ctypes.data_as(ip), len(F), float(z0), _p(xy), n.value, C.byref(n),
+                              sizes.ctypes.data_as(ip), nl.value, C.byref(nl))
+    if rc:
+        raise SvsdfError("svsdf_mesh_section failed: " + L.svsdf_last_error_string(None).decode())
+    return xy, [int(v) for v in sizes]
+
+
+def mesh_section_obj(path, z0=0.0):
+    """The same for a Wavefront .obj file (svsdf_mesh_section_obj)."""
+    L = lib()
+    n, nl = C.c_size_t(), C.c_size_t()
+    ip = C.POINTER(C.c_int)
+    L.svsdf_mesh_section_obj.argtypes = [C.c_char_p, C.c_double, _dp, C.c_size_t, C.POINTER(C.c_size_t), ip, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
+    path = os.fspath(path)
+    rc = L.svsdf_mesh_section_obj(path.encode(), float(z0), None, 0, C.byref(n), None, 0, C.byref(nl))
+    if rc:
+        raise SvsdfError("svsdf_mesh_section_obj failed: " + L.svsdf_last_error_string(None).decode())
+    xy = np.zeros((n.value, 2))
+    sizes = np.zeros(nl.value, dtype=np.int32)
+    rc = L.svsdf_mesh_section_obj(path.encode(), float(z0), _p(xy), n.value, C.byref(n), sizes.ctypes.data_as(ip), nl.value,
+                                  C.byref(nl))
+    if rc:
+        raise SvsdfError("svsdf_mesh_section_obj failed: " + L.svsdf_last_error_string(None).decode())
+    return xy, [int(v) for v in sizes]
+
+
 def mesh_outline_obj(path, z0=0.0):
     """Same from a Wavefront .obj file (svsdf_mesh_outline_obj)."""
     n, loops = C.c_size_t(), C.c_int()
@@ -392,7 +435,8 @@ class SvsdfContext:
 
     def __init__(self, shape="star", safety_hor=0.7, weight_p=60.0, rho=3.8,
                  poly_params=(0.0, 0.0, 0.0), polygon=None, head_state=None, tail_state=None,
-                 device=-1, rank=0, world_size=1, flags=0, devices=None, combine=COMBINE_AUTO):
+                 device=-1, rank=0, world_size=1, flags=0, devices=None, combine=COMBINE_AUTO, polygon_loops=None):
+        """polygon_loops: vertex counts of the closed loops `polygon` is made of (mesh_section); None: one loop."""
         self.L = lib()
         cfg = Config()
         self.L.svsdf_config_default(C.byref(cfg))
@@ -416,6 +460,10 @@ class SvsdfContext:
             self._poly = _f64(polygon).reshape(-1, 2).copy()
             cfg.polygon_nverts = len(self._poly)
             cfg.polygon_xy = _p(self._poly)
+            if polygon_loops is not None and len(polygon_loops) >= 2:
+                self._loops = (C.c_int * len(polygon_loops))(*[int(v) for v in polygon_loops])
+                cfg.polygon_nloops = len(polygon_loops)
+                cfg.polygon_loop_sizes = C.cast(self._loops, C.POINTER(C.c_int))
         h = self.L.svsdf_create(C.byref(cfg))
         if not h:
             raise SvsdfError("svsdf_create failed: " + self.L.svsdf_last_error_string(None).decode())

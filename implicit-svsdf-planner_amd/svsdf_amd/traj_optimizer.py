@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from .binding import SvsdfContext, SvsdfError, shape_id_from_inputdata, SHAPES, mesh_outline_obj
+from .binding import SvsdfContext, SvsdfError, shape_id_from_inputdata, SHAPES, mesh_section_obj
 
 
 def _dist():
@@ -38,6 +38,7 @@ class TrajOptimizer:
         self.inputdata = "shapes/star.obj"
         self.poly_params = (0.0, 0.0, 0.0)
         self.polygon = None
+        self.polygon_loops = None   # with `polygon`: vertex counts of its closed loops (None: one loop)
         self.package_path = ""         # what ros::package::getPath("plan_manager") returns (Shape.hpp:283)
         self.parallel_points = np.zeros((0, 3))
         self.parallel_points_num = 0
@@ -64,6 +65,7 @@ class TrajOptimizer:
         self.inputdata = config.get("inputdata", self.inputdata)
         self.poly_params = tuple(config.get("poly_params", self.poly_params))
         self.polygon = config.get("polygon", self.polygon)
+        self.polygon_loops = config.get("polygon_loops", self.polygon_loops)
         self.package_path = config.get("package_path", self.package_path)
         self.device = int(config.get("device", self.device))
         self.devices = config.get("devices", self.devices)
@@ -92,24 +94,21 @@ class TrajOptimizer:
         if self._ctx is None:
             sid = shape_id_from_inputdata(self.inputdata) if self.polygon is None else SHAPES.index("Polygon")
             polygon = self.polygon
+            polygon_loops = getattr(self, "polygon_loops", None)
             if sid == SHAPES.index("Polygon") and polygon is None:
                 # an .obj the shape registry does not know (BASELINE config 5): its z = 0 outline; unreadable -> the
                 # reference's hard-coded rectangle (sw_manager.hpp:363-369), which the library substitutes itself
                 path = os.path.join(self.package_path, self.inputdata) if self.package_path else self.inputdata
                 if os.path.exists(path):
-                    polygon, loops = mesh_outline_obj(path)
-                    if loops != 1:
-                        # several loops (disjoint bodies, a hole): planning with one of them would silently drop part of
-                        # the robot -- its collisions would go unpenalised
-                        raise SvsdfError(f"{path}: the z = 0 cross-section has {loops} closed loops; the Polygon shape "
-                                         "takes exactly one outline (pass `polygon=` explicitly to choose)")
+                    # the whole section: every closed loop (a hole, several solids; round 5 -- rounds 3-4 refused them)
+                    polygon, polygon_loops = mesh_section_obj(path)
             dist = _dist()
             rank, ws = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
             self._ctx = SvsdfContext(shape=sid, safety_hor=self.safety_hor, weight_p=self.weight_p,
                                      rho=self.rho, poly_params=self.poly_params, polygon=polygon,
                                      head_state=self.initState, tail_state=self.finalState,
                                      device=self.device, rank=rank, world_size=ws,
-                                     devices=self.devices, combine=self.combine)
+                                     devices=self.devices, combine=self.combine, polygon_loops=polygon_loops)
             self._points_dirty = True
         if self._points_dirty:
             self._ctx.set_points(self.parallel_points)

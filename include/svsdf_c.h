@@ -51,7 +51,8 @@ enum svsdf_shape_id {
 };
 
 #define SVSDF_MAX_PIECES 64        /* MINCO pieces per trajectory handled on the device */
-#define SVSDF_MAX_POLY_VERTS 4096  /* Polygon outline vertices (the z = 0 outlines of the reference meshes have 77 ... 754) */
+#define SVSDF_MAX_POLY_VERTS 8190  /* Polygon outline vertices + one per loop of a multi-loop outline (the z = 0 outlines of
+                                      the reference meshes have 77 ... 754) */
 #define SVSDF_MAX_DEVICES 8        /* GPUs one context can drive (one xGMI node) */
 
 /* Error codes (0 = ok).  HIP runtime errors are returned as SVSDF_ERR_HIP_BASE + hipError_t. */
@@ -93,6 +94,13 @@ typedef struct svsdf_config {
   int n_devices;
   int devices[SVSDF_MAX_DEVICES];
   int combine;               /* SVSDF_COMBINE_*: how the per-device partials are summed */
+  /* Polygon of several closed loops (a mesh section with a hole, two solids; svsdf_mesh_section): polygon_xy holds the
+   * loops one after the other, polygon_loop_sizes[k] (>= 3) vertices each, summing to polygon_nverts.  The reference's
+   * Polygon::getonlySDF (Shape.hpp:1448-1476) is the minimum of dis2Seg over all edges, negated on an odd count of
+   * isCrossRayOnXDir over all edges: it does not care how the edges are chained, so the union of the loops' edges is
+   * evaluated exactly like its single chain.  polygon_nloops <= 1 (or a NULL pointer): one loop, as the reference. */
+  int polygon_nloops;
+  const int *polygon_loop_sizes;
 } svsdf_config;
 
 #define SVSDF_COMBINE_AUTO 0 /* = HOST (measured: DESIGN.md "Multi-GPU") */
@@ -292,6 +300,13 @@ int svsdf_mesh_outline(const double *V, size_t nv, const int *F, size_t nf, doub
                        size_t capacity_verts, size_t *count, int *loops);
 int svsdf_mesh_outline_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *count,
                            int *loops);
+/* The whole section: every closed loop of z = z0, largest enclosed area first, as svsdf_config::polygon_xy /
+ * polygon_loop_sizes / polygon_nloops take them (the planner then sees holes and separate solids, not just the largest
+ * loop).  xy_out and loop_sizes may both be NULL to query the counts. */
+int svsdf_mesh_section(const double *V, size_t nv, const int *F, size_t nf, double z0, double *xy_out, size_t capacity_verts,
+                       size_t *n_verts, int *loop_sizes, size_t capacity_loops, size_t *n_loops);
+int svsdf_mesh_section_obj(const char *obj_path, double z0, double *xy_out, size_t capacity_verts, size_t *n_verts,
+                           int *loop_sizes, size_t capacity_loops, size_t *n_loops);
 
 /* ---- swept-volume outline -------------------------------------------------------------------------------
  * What the reference's (unused) swept-volume surface extraction is for -- SweptVolumeManager::calculateSwept

@@ -44,9 +44,10 @@ class TrajOptimizerHip {
   std::string inputdata = "shapes/star.obj";
   double poly_params[3] = {0.0, 0.0, 0.0};
   std::string package_path;        // what ros::package::getPath("plan_manager") returns (Shape.hpp:283): prefix of inputdata
-  std::string mesh_error;          // why context() returned nullptr for a mesh `inputdata` (cross-section with several loops)
+  std::string mesh_error;          // why context() returned nullptr for a mesh `inputdata` (cross-section too large)
   std::vector<double> polygon_xy;  // optional outline for the Polygon fallback; empty + an inputdata stem the shape
-                                   // registry does not know -> the z = 0 outline of that .obj mesh (BASELINE config 5)
+                                   // registry does not know -> the z = 0 section of that .obj mesh (BASELINE config 5)
+  std::vector<int> polygon_loops;  // with polygon_xy: vertices per closed loop (empty: one loop)
   int device = -1;
   int rank = 0, world_size = 1;
   std::vector<int> devices;        // >= 2 entries: in-process multi-GPU (svsdf_config::n_devices / devices); 1 entry: that device
@@ -180,17 +181,18 @@ class TrajOptimizerHip {
       svsdf_config_default(&cfg);
       cfg.shape_id = polygon_xy.empty() ? svsdf_shape_id_from_inputdata(inputdata.c_str()) : (int)SVSDF_SHAPE_Polygon;
       std::vector<double> outline = polygon_xy;
+      std::vector<int> loop_sizes = polygon_loops;
       if (cfg.shape_id == SVSDF_SHAPE_Polygon && outline.empty()) {
-        // an .obj the shape registry does not know: its z = 0 outline (the reference reads the same file with
-        // igl::read_triangle_mesh, Shape.hpp:281-284); unreadable -> the reference's hard-coded rectangle (SWM:363-369)
+        // an .obj the shape registry does not know: its whole z = 0 section -- every closed loop (a hole, several solids:
+        // round 5; rounds 3-4 refused such meshes) -- (the reference reads the same file with igl::read_triangle_mesh,
+        // Shape.hpp:281-284); unreadable -> the reference's hard-coded rectangle (SWM:363-369)
         const std::string path = package_path.empty() ? inputdata : package_path + "/" + inputdata;
-        std::size_t n = 0;
-        int loops = 0;
-        if (svsdf_mesh_outline_obj(path.c_str(), 0.0, nullptr, 0, &n, &loops) == SVSDF_OK && n >= 3) {
-          // several loops (disjoint bodies, a hole): planning with one of them would silently drop part of the robot
-          if (loops != 1) { mesh_error = path + ": the z = 0 cross-section has " + std::to_string(loops) + " closed loops"; return nullptr; }
+        std::size_t n = 0, nl = 0;
+        if (svsdf_mesh_section_obj(path.c_str(), 0.0, nullptr, 0, &n, nullptr, 0, &nl) == SVSDF_OK && n >= 3) {
+          if (n + nl > (std::size_t)SVSDF_MAX_POLY_VERTS) { mesh_error = path + ": the z = 0 cross-section has " + std::to_string(n) + " vertices (max " + std::to_string(SVSDF_MAX_POLY_VERTS) + ")"; return nullptr; }
           outline.resize(2 * n);
-          if (svsdf_mesh_outline_obj(path.c_str(), 0.0, outline.data(), n, &n, nullptr) != SVSDF_OK) outline.clear();
+          loop_sizes.resize(nl);
+          if (svsdf_mesh_section_obj(path.c_str(), 0.0, outline.data(), n, &n, loop_sizes.data(), nl, &nl) != SVSDF_OK) { outline.clear(); loop_sizes.clear(); }
         }
       }
       std::memcpy(cfg.poly_params, poly_params, sizeof(poly_params));
@@ -206,6 +208,8 @@ class TrajOptimizerHip {
       }
       cfg.polygon_nverts = (int)(outline.size() / 2);
       cfg.polygon_xy = outline.empty() ? nullptr : outline.data();
+      cfg.polygon_nloops = (loop_sizes.size() >= 2) ? (int)loop_sizes.size() : 0;
+      cfg.polygon_loop_sizes = (loop_sizes.size() >= 2) ? loop_sizes.data() : nullptr;
       ctx_ = svsdf_create(&cfg);
       built_key_ = key;
       points_dirty_ = true;
@@ -228,6 +232,8 @@ class TrajOptimizerHip {
     if (!devices.empty()) add(devices.data(), devices.size() * sizeof(int));
     k += "|";
     if (!polygon_xy.empty()) add(polygon_xy.data(), polygon_xy.size() * sizeof(double));
+    k += "|";
+    if (!polygon_loops.empty()) add(polygon_loops.data(), polygon_loops.size() * sizeof(int));
     return k;
   }
   std::string built_key_;

@@ -8,9 +8,44 @@
 
 using namespace svsdf;
 
+#include <chrono>
+#include <cstring>
+
 static int g_refine = SVSDF_POLY_REFINE;
+static std::vector<int> g_loops;   // loop sizes of the outlines given to the calls below (empty: one loop)
+
+static bool build(const double *xy, int n, PolyAccelHost &h) {
+  return build_poly_accel(xy, n, h, 128, 256, 256, g_refine, 32, g_loops.empty() ? nullptr : g_loops.data(), (int)g_loops.size());
+}
 
 extern "C" {
+
+// outline of several closed loops (sizes add up to n) for the calls below; nloops = 0: back to one loop
+void polyhost_set_loops(const int *sizes, int nloops) { g_loops.assign(sizes, sizes + (nloops > 0 ? nloops : 0)); }
+
+// FNV-1a over everything build_poly_accel produces (edges, cell / slab records, long lists, the header's numbers) and the
+// wall time of the build
+int polyhost_build_hash(const double *xy, int n, unsigned long long *hash_out, double *ms_out, long long *sizes_out) {
+  PolyAccelHost h;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!build(xy, n, h)) return 1;
+  *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  unsigned long long f = 1469598103934665603ull;
+  auto add = [&](const void *p, size_t bytes) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < bytes; ++i) { f ^= b[i]; f *= 1099511628211ull; }
+  };
+  add(h.edges.data(), h.edges.size() * sizeof(PolyEdge));
+  add(h.cells.data(), h.cells.size() * sizeof(PolyRec));
+  add(h.slabs.data(), h.slabs.size() * sizeof(PolyRec));
+  add(h.over.data(), h.over.size() * sizeof(unsigned short));
+  PolyAccel hdr = h.hdr;
+  hdr.edges = nullptr; hdr.cells = nullptr; hdr.slabs = nullptr; hdr.over = nullptr;
+  add(&hdr, sizeof hdr);
+  *hash_out = f;
+  if (sizes_out) { sizes_out[0] = (long long)h.edges.size(); sizes_out[1] = (long long)h.cells.size(); sizes_out[2] = (long long)h.over.size(); sizes_out[3] = (long long)h.cand_total; }
+  return 0;
+}
 
 // second-pass resolution of the candidate lists for the calls below (1 = first pass only)
 void polyhost_set_refine(int r) { g_refine = r; }
@@ -20,7 +55,7 @@ void polyhost_set_refine(int r) { g_refine = r; }
 int polyhost_eval(const double *xy, int n, const double *pts, size_t P, double *sdf_out, double *sdfc_out,
                   double *closest_out, long long *stats_out) {
   PolyAccelHost h;
-  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
+  if (!build(xy, n, h)) return 1;
   PolyAccel pa = h.hdr;
   pa.edges = h.edges.data();
   pa.cells = h.cells.data();
@@ -45,7 +80,7 @@ int polyhost_eval(const double *xy, int n, const double *pts, size_t P, double *
 // which list a query uses: 0 fine grid, 1 coarse grid, 2 far grid, 3 full loop; and how many edges it visits
 int polyhost_visits(const double *xy, int n, const double *pts, size_t P, int *level_out, int *count_out) {
   PolyAccelHost h;
-  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
+  if (!build(xy, n, h)) return 1;
   for (size_t i = 0; i < P; ++i) {
     unsigned base = 0;
     const int cell = poly_locate(h.hdr, pts[2 * i], pts[2 * i + 1], base);
@@ -60,7 +95,7 @@ int polyhost_visits(const double *xy, int n, const double *pts, size_t P, int *l
 // how many edges the crossing-parity loop of a query visits (0 when no edge can cross its ray)
 int polyhost_parity_visits(const double *xy, int n, const double *pts, size_t P, int *count_out) {
   PolyAccelHost h;
-  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
+  if (!build(xy, n, h)) return 1;
   const PolyAccel &pa = h.hdr;
   for (size_t i = 0; i < P; ++i) {
     const double x = pts[2 * i], y = pts[2 * i + 1];
@@ -96,7 +131,7 @@ void polyhost_quot(const double *a, const double *b, size_t m, double *q_out, in
 // rect_out[4 i ..] = x0, y0, x1, y1 (NaN when the query is outside all levels); level_out: 0 fine, 1 coarse, 2 far, 3 none
 int polyhost_cell_rect(const double *xy, int n, const double *pts, size_t P, double *rect_out, int *level_out) {
   PolyAccelHost h;
-  if (!build_poly_accel(xy, n, h, 128, 256, 256, g_refine)) return 1;
+  if (!build(xy, n, h)) return 1;
   for (size_t i = 0; i < P; ++i) {
     unsigned base = 0;
     const int cell = poly_locate(h.hdr, pts[2 * i], pts[2 * i + 1], base);
