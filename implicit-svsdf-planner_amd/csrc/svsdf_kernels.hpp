@@ -33,6 +33,9 @@ namespace svsdf {
 #ifndef SVSDF_ELASTIC
 #define SVSDF_ELASTIC 1   // the descent's halving ladders share the wave's lanes (descend_from_seed)
 #endif
+#ifndef SVSDF_FUSED_PASS
+#define SVSDF_FUSED_PASS 1   // a wave's LAST open descent: derivative + both signs of the ladder in one step (descend_from_seed)
+#endif
 constexpr int kMaxPieces = 64;
 constexpr int kMaxSlots = 24;   // GSIP samples per round: 2, 6, 18, 21, 21, ... (SWM:60-71,105-110)
 constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
@@ -921,7 +924,64 @@ __device__ __forceinline__ void descend_from_seed(const TrajL &tr, const double 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (run) run = iter < 1000 && fabs(mine_gs->x - mine_gs->prev_x) > 1e-16;
-        if (__ballot(run) == 0ull) break;
+        const unsigned long long runm = __ballot(run && li == 0);
+        if (runm == 0ull) break;
+#if SVSDF_FUSED_PASS
+        if (__popcll(runm) == 1) {
+          // ONE descent left in the wave (round 5; the rule at the reference's scale, where a wave holds one or two queries:
+          // a callback there is ~ 230 dependent evaluation steps of ~ 2 us each, and a pass was two of them -- the FD
+          // derivative, then the ladder).  The ladder's candidates depend on the derivative only through its SIGN, so both
+          // signs are evaluated with it in one step: lanes 0 .. 2 the derivative's tasks, lanes 3 .. 31 the candidates x - tau_j
+          // (j = 1 .. 29), lanes 35 .. 63 the candidates x + tau_j; afterwards the sign picks its half, whose first accepted
+          // candidate is the one the sequential loop accepts.  Same operations on the same operands: same bits; the other
+          // half's 29 evaluations are counted as speculative.  A wave with several open descents keeps the two-step pass
+          // (its lanes are busy with the other ladders).
+          const int srcg = (__ffsll((long long)runm) - 1) / G;
+          LadderState *S = gs + srcg;
+          const double x = S->x, qx = S->px, qy = S->py, sseed = S->seed;
+          PieceCache pcs;
+          pcs.piece = S->piece; pcs.lo = S->lo; pcs.hi = S->hi;
+          const int ntask = first_pass ? 3 : 2;
+          const bool is_task = lane < ntask;
+          const bool is_cand = (lane >= 3 && lane < 32) || lane >= 35;
+          const int j = (lane < 32) ? lane - 2 : lane - 34;             // div (candidates)
+          const double ssgn = (lane < 32) ? 1.0 : -1.0;
+          const double stmin = dmax(0.0, sseed - 3.4), stmax = dmin(sseed + 3.4, tr.dur);
+          const double tau = ldexp(0.01, 1 - j);
+          const double change = -tau * ssgn;
+          double xc = x + change;
+          xc = dmax(dmin(xc, stmax), stmin);
+          const double t1 = dmax(0.0, x - 0.000001);
+          const double t2 = dmin(tr.dur, x + 0.000001);
+          const double tt = is_task ? ((lane == 0) ? t1 : (lane == 1) ? t2 : x) : xc;
+          double d = inf;
+          SVSDF_SITE(sc, 3, is_task || is_cand);
+          if (is_task || is_cand) { d = sdf_at<SHAPE>(tr, sp, qx, qy, tt, pcs); ++n_eval; }
+          const double sdf1 = __shfl(d, 0, 64), sdf2 = __shfl(d, 1, 64), f0 = __shfl(d, 2, 64);
+          const double g = (sdf2 - sdf1) * 500000;
+          const int sgn = (int)(g > 0) - (int)(g < 0);
+          const double sfx = first_pass ? f0 : S->fx;
+          const unsigned long long accm = __ballot(is_cand && (d - sfx) < 0);
+          const unsigned bits = (sgn > 0) ? (unsigned)((accm >> 3) & 0x1fffffffull) : (sgn < 0) ? (unsigned)((accm >> 35) & 0x1fffffffull) : 0u;
+          const int jacc = bits ? __ffs(bits) : 0;                       // accepted div (1 .. 29), 0: none
+          // lane 0 evaluated at t1 = x - 1e-6: its piece interval is the next pass's starting point (as in the two-step pass)
+          const int p0 = __shfl(pcs.piece, 0, 64);
+          const double lo0 = __shfl(pcs.lo, 0, 64), hi0 = __shfl(pcs.hi, 0, 64);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {
+            S->sgn = sgn; S->prev_x = x; S->piece = p0; S->lo = lo0; S->hi = hi0;
+            if (first_pass && !jacc) S->fx = f0;
+          }
+          if (is_cand && jacc && j == jacc && ((sgn > 0) == (lane < 32))) { S->x = xc; S->fx = d; }
+          if (is_cand) n_spec += (jacc && ((sgn > 0) == (lane < 32)) && sgn != 0) ? (j > jacc ? 1u : 0u) : 1u;
+          if (run) {   // the owning group's bookkeeping (SWM:1295-1321): trials of this ladder, stop when none was accepted
+            iter += jacc ? jacc : 29;
+            if (!jacc) run = false;
+          }
+          continue;
+        }
+#endif
         if (run) {
           // tasks: 0 -> sdf(t1), 1 -> sdf(t2), 2 -> sdf(x) (first pass only)
           const double x = mine_gs->x, qx = mine_gs->px, qy = mine_gs->py;

@@ -59,6 +59,26 @@ __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fm
 __device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
 #endif
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return dmax(dmin(v, hi), lo); }
+
+// a / b for a shape CONSTANT b (round 5): the quotient the division instruction sequence rounds to, from rb = RN(1 / b) (folded
+// at compile time) by poly_quot's two residual steps -- five full-rate operations instead of the division's thirteen with
+// a quarter-rate v_rcp_f64 (svsdf_polygon.hpp: Markstein's theorem; the same function the Polygon edges use, checked against
+// the division on adversarial operands by tests/test_polygon_accel.py and, for these constants, tests/test_const_div.py).
+// |a| outside [1e-150, 1e150] (a zero, a NaN, an infinity) takes the division itself, wave-uniformly.
+#ifndef SVSDF_CONST_DIV
+#define SVSDF_CONST_DIV 1
+#endif
+__device__ __forceinline__ double div_const(double a, double b, double rb) {
+#if SVSDF_CONST_DIV
+  bool inr;
+  double q = poly_quot(a, b, rb, inr);
+  if (SVSDF_WAVE_ANY(!inr)) q = inr ? q : a / b;
+  return q;
+#else
+  (void)rb;
+  return a / b;
+#endif
+}
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
 
 // SHP:531-543
@@ -84,12 +104,13 @@ __device__ __forceinline__ double sdf_cut_disk(double px, double py) {
 
 // SHP:754-767
 __device__ __forceinline__ double sdf_trapezoid(double px, double py) {
-  const double r1 = 1.0, r2 = 3.0, he = 2.0;
-  const double k1x = r2, k1y = he, k2x = r2 - r1, k2y = 2.0 * he;
+  constexpr double r1 = 1.0, r2 = 3.0, he = 2.0;
+  constexpr double k1x = r2, k1y = he, k2x = r2 - r1, k2y = 2.0 * he;
   px = fabs(px);
   const double cax = dmax(0.0, px - ((py < 0.0) ? r1 : r2));
   const double cay = fabs(py) - he;
-  const double c = clipd(((k1x - px) * k2x + (k1y - py) * k2y) / (k2x * k2x + k2y * k2y), 0.0, 1.0);
+  constexpr double den = k2x * k2x + k2y * k2y;
+  const double c = clipd(div_const((k1x - px) * k2x + (k1y - py) * k2y, den, 1.0 / den), 0.0, 1.0);
   const double cbx = (px - k1x) + k2x * c;
   const double cby = (py - k1y) + k2y * c;
   const double s = (cbx < 0.0 && cay < 0.0) ? -1.0 : 1.0;
@@ -98,12 +119,12 @@ __device__ __forceinline__ double sdf_trapezoid(double px, double py) {
 
 // SHP:809-826
 __device__ __forceinline__ double sdf_rhombus(double px, double py) {
-  const double bx = 1.0, by = 4.5;
+  constexpr double bx = 1.0, by = 4.5;
   px = fabs(px);
   py = fabs(py);
   const double mbx = bx - 2.0 * px, mby = by - 2.0 * py;
-  const double dp = bx * bx + by * by;
-  const double h = clipd((mbx * bx - mby * by) / dp, -1.0, 1.0);
+  constexpr double dp = bx * bx + by * by;
+  const double h = clipd(div_const(mbx * bx - mby * by, dp, 1.0 / dp), -1.0, 1.0);
   const double bhx = 0.5 * bx, bhy = 0.5 * by;
   const double vhx = 1.0 - h, vhy = 1.0 + h;
   const double d = norm2(px - bhx * vhx, py - bhy * vhy);
@@ -114,8 +135,8 @@ __device__ __forceinline__ double sdf_rhombus(double px, double py) {
 
 // SHP:584-601
 __device__ __forceinline__ double sdf_star(double px, double py) {
-  const double r = 2.8, rf = 0.6;
-  const double k1x = 0.809016994375, k1y = -0.587785252292;
+  constexpr double r = 2.8, rf = 0.6;
+  constexpr double k1x = 0.809016994375, k1y = -0.587785252292;
   const double k2x = -k1x, k2y = k1y;
   px = fabs(px);
   double s = 2.0 * dmax(k1x * px + k1y * py, 0.0);
@@ -126,9 +147,10 @@ __device__ __forceinline__ double sdf_star(double px, double py) {
   py -= s * k2y;
   px = fabs(px);
   py -= r;
-  const double bax = rf * (-k1y) - 0.0;
-  const double bay = rf * k1x - 1.0;
-  const double h = clipd((px * bax + py * bay) / (bax * bax + bay * bay), 0.0, r);
+  constexpr double bax = rf * (-k1y) - 0.0;
+  constexpr double bay = rf * k1x - 1.0;
+  constexpr double bb = bax * bax + bay * bay;
+  const double h = clipd(div_const(px * bax + py * bay, bb, 1.0 / bb), 0.0, r);
   const double dx = px - bax * h, dy = py - bay * h;
   return norm2(dx, dy) * copysign(1.0, py * bax - px * bay);
 }

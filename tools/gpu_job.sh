@@ -8,6 +8,8 @@
 #   site:<lib>[:<configs>]   tools/site_stats.py of a -DSVSDF_SITE_STATS variant build (default C3,NS; ref:star = reference scale)
 #   bench        bench.py default line (N = 1)
 #   benchq       bench.py --no-extras --no-cpu-baseline (headline only)
+#   benchv:<variant>   the same with libsvsdf_hip_<variant>.so (SVSDF_LIB_VARIANT)
+#   abenv:<spec>[:<configs>[:<points>]]   tools/ab_env.py on the default library ("A=1;B=2": first spec = baseline)
 #   stripes8     bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config C4 (8 stripes on this GPU)
 #   ab:<variants>[:<configs>[:<points>]]   tools/exp_variants.py (variant builds vs the default library, identity hash)
 #   pytest[:<expr>]   pytest -m gpu [-k expr]
@@ -37,6 +39,8 @@ for STEP in "$@"; do
     site)     IFS=: read -r V C <<< "$ARG"; timeout 400 python -u tools/site_stats.py ${V:-st} ${C:-C3,NS} > $OUT/${TAG}_site_${V:-st}.txt 2>&1 ;;
     bench)    timeout 900 python -u bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err ;;
     benchq)   timeout 300 python -u bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_quick.json 2> $OUT/${TAG}_bench_quick.err ;;
+    benchv)   SVSDF_LIB_VARIANT=$ARG timeout 300 python -u bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_quick_$ARG.json 2> $OUT/${TAG}_bench_quick_$ARG.err ;;
+    abenv)    IFS=: read -r SPEC C P <<< "$ARG"; timeout 600 python -u tools/ab_env.py - "$SPEC" ${C:-C3,NS} ${P:-0} > $OUT/${TAG}_abenv.txt 2>&1 ;;
     stripes8) timeout 600 python -u bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config C4 --steps 10 --no-extras > $OUT/${TAG}_stripes8.json 2> $OUT/${TAG}_stripes8.err ;;
     ab)       IFS=: read -r V C P <<< "$ARG"; timeout 900 python -u tools/exp_variants.py "$V" ${C:-C3,NS} ${P:-1000000} > $OUT/${TAG}_ab_$(echo $V | tr ',' '_').txt 2>&1 ;;
     pytest)   if [ -n "$ARG" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$ARG" > $OUT/${TAG}_pytest.txt 2>&1; else timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_pytest.txt 2>&1; fi; tail -3 $OUT/${TAG}_pytest.txt ;;
