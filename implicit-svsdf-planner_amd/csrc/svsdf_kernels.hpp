@@ -1215,7 +1215,10 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   const int li = Grp<G>::li();
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_culled = 0, n_spec = 0;
   unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
-  const bool clk_probe = work_idx == 0 && blockIdx.x == 0 && threadIdx.x < 64;   // (wave-uniform; BatchCtl::clk)
+#ifndef SVSDF_CLOCK_PROBE
+#define SVSDF_CLOCK_PROBE 1
+#endif
+  const bool clk_probe = SVSDF_CLOCK_PROBE && work_idx == 0 && blockIdx.x == 0 && threadIdx.x < 64;   // (wave-uniform; BatchCtl::clk)
   const long long clk_c0 = clk_probe ? clock64() : 0ll, clk_r0 = clk_probe ? wall_clock64() : 0ll;
   // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
   // the launch's cursor.  (All waves of a launch start together: with a fetch first, their 3000 atomics on one address
@@ -2323,7 +2326,7 @@ __device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, c
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
            const double *__restrict__ res_t, const double *__restrict__ res_gx,
            const double *__restrict__ res_gy, double safety_hor, double weight_p,
-           double *__restrict__ block_partials, int *__restrict__ nonfinite, double *asm_lds) {
+           double *__restrict__ block_partials, int *__restrict__ nonfinite, double *asm_lds, bool keep_in_lds = false) {
   // Deterministic (bit-reproducible run to run): no floating-point atomics.  Every wave owns a private
   // accumulator row in LDS; per grid-stride step the wave walks the distinct piece ids among its active lanes
   // (lowest lane first), sums each of the 20 per-point terms of that piece with a fixed xor butterfly (every
@@ -2427,6 +2430,7 @@ __device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, c
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += acc_all[(size_t)w * plen + e];
     block_partials[(size_t)e * gridDim.x + blockIdx.x] = s;
+    if (keep_in_lds) acc_all[e] = 0.0 + s;   // (a one-block grid: k_final's sum of this entry, for k_reduce -- in place of row 0)
   }
 }
 
@@ -2499,10 +2503,18 @@ __device__ __forceinline__ void finish_body(const double *__restrict__ sums, int
   }
 }
 
+// (host_out / out_doubles: the pinned host buffer the whole result -- partial + counters, laid out like `partial` -- is also
+// written to, or null)
 __global__ void k_finish(const double *__restrict__ sums, int N, double *__restrict__ partial,
                          const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
-                         const int *__restrict__ nonfinite, unsigned long long *__restrict__ stats_out) {
+                         const int *__restrict__ nonfinite, unsigned long long *__restrict__ stats_out,
+                         double *__restrict__ host_out, int out_doubles) {
   finish_body(sums, N, partial, ctl, nbatch, it_end, nonfinite, stats_out);
+  if (host_out) {
+    __threadfence();
+    __syncthreads();
+    for (int k = threadIdx.x; k < out_doubles; k += blockDim.x) host_out[k] = partial[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2512,34 +2524,39 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
 // straight into the pinned host buffer: one launch and no copy command where the evaluation's tail was three launches and a
 // device-to-host copy (64 us + 10 us of the 490 us a reference-scale callback took).  Same additions in the same order as the
 // three kernels: same bits.  `ticket` counts finished blocks; the last block resets it.
+// fuse == 0 (grids of more than 4 blocks): assembly only -- one block summing 19N+1 entries over hundreds of block partials
+// is a serial tail (57 us at C3's 512 blocks against k_final's 5 us with one wave PER entry): k_final and k_finish follow
+// as launches of their own there, where two launches are nothing against the evaluation.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_reduce(const TrajDev *__restrict__ trg, const double *__restrict__ px_, const double *__restrict__ py_, int P,
          const double *__restrict__ res_sdf, const double *__restrict__ res_t, const double *__restrict__ res_gx,
          const double *__restrict__ res_gy, double safety_hor, double weight_p, double *__restrict__ block_partials,
          int *__restrict__ nonfinite, double *__restrict__ out, const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
-         int out_partial, int out_doubles, unsigned *__restrict__ ticket, double *__restrict__ host_out) {
+         int out_partial, int out_doubles, unsigned *__restrict__ ticket, double *__restrict__ host_out, int fuse) {
   extern __shared__ double asm_lds[];
   __shared__ unsigned s_last;
-  assemble_body(trg, px_, py_, P, res_sdf, res_t, res_gx, res_gy, safety_hor, weight_p, block_partials, nonfinite, asm_lds);
+  const bool one_block = gridDim.x == 1;   // up to 256 points (the reference's demo maps give 101 .. 139): nothing to wait for
+  assemble_body(trg, px_, py_, P, res_sdf, res_t, res_gx, res_gy, safety_hor, weight_p, block_partials, nonfinite, asm_lds, fuse && one_block);
+  if (!fuse) return;
+  const int N = trg->N;
+  const int plen = 19 * N + 1;
+  const int nblocks = (int)gridDim.x;
+  double *sums = asm_lds + traj_lds_doubles(N);   // (the accumulator rows are free again: plen <= 4 plen doubles)
+  if (!one_block) {
   __threadfence();   // this block's partials (and its non-finite count) are visible device-wide before its ticket is
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  const int N = trg->N;
-  const int plen = 19 * N + 1;
-  const int nblocks = (int)gridDim.x;
-  double *sums = asm_lds + traj_lds_doubles(N);   // (the accumulator rows are free again: plen <= 4 plen doubles)
-  const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
   // (other blocks wrote the partials: read at device scope, past this CU's vector cache)
   auto part = [&](int e, int b) { return __hip_atomic_load(&block_partials[(size_t)e * nblocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  if (nblocks <= 4) {
+  {
     // Up to 1024 points (the reference's own scale): one THREAD per entry.  k_final's wave leaves in lane 0, for lane
-    // values p_b = 0.0 + partial[e][b] (b < nblocks, zero beyond), the tree ((p0 + p2) + (p1 + p3)) -- the xor steps 32 .. 4
-    // only add zeros to lanes 0 .. 3 -- so the same bits come from four independent loads per thread instead of a dependent
-    // load + butterfly per entry, one entry after the other (that loop cost 60 us of a 480 us callback at 101 points).
+    // values p_b = 0.0 + partial[e][b] (b < nblocks <= 4, zero beyond), the tree ((p0 + p2) + (p1 + p3)) -- the xor steps
+    // 32 .. 4 only add zeros to lanes 0 .. 3 -- so the same bits come from four independent loads per thread instead of a
+    // dependent load + butterfly per entry, one entry after the other (that loop cost 60 us of a 480 us callback).
     for (int e = threadIdx.x; e < plen; e += blockDim.x) {
       double p[4];
 #pragma unroll
@@ -2548,35 +2565,15 @@ k_reduce(const TrajDev *__restrict__ trg, const double *__restrict__ px_, const 
       for (int r = 0; r < 4; ++r) { p[0] += 0.0; p[1] += 0.0; p[2] += 0.0; p[3] += 0.0; }   // xor 32, 16, 8, 4: the partners hold zeros
       sums[e] = (p[0] + p[2]) + (p[1] + p[3]);                                             // xor 2, then xor 1
     }
-  } else {
-    // one wave per entry as in k_final, eight entries in flight per wave (independent loads, interleaved butterflies)
-    constexpr int UN = 8;
-    for (int e0 = wv * UN; e0 < plen; e0 += (kBlock / 64) * UN) {
-      double s[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        s[u] = 0.0;
-        if (e0 + u < plen)
-          for (int b = lane; b < nblocks; b += 64) s[u] += part(e0 + u, b);
-      }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) s[u] += __shfl_xor(s[u], m, 64);
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) if (e0 + u < plen) sums[e0 + u] = s[u];
-      }
-    }
   }
+  }  // !one_block (one block: assemble_body left sums[e] = 0.0 + its partial in place)
   __syncthreads();
   finish_body(sums, N, out, ctl, nbatch, it_end, nonfinite, reinterpret_cast<unsigned long long *>(out + out_partial));
   __threadfence();
   __syncthreads();
   if (host_out)
     for (int k = threadIdx.x; k < out_doubles; k += blockDim.x) host_out[k] = out[k];
-  if (threadIdx.x == 0) *ticket = 0u;
+  if (threadIdx.x == 0 && !one_block) *ticket = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -561,18 +561,27 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
       ctx->block_partials_cap = (size_t)grid * plen;
     }
     const size_t lds = ((size_t)traj_lds_doubles(N) + (kBlock / 64) * plen) * sizeof(double);  // one accumulator row per wave
-    // assembly, block reduction, fixed-order final sum, suffix sum and counters in ONE launch; the last block writes the
-    // result to the device buffer and straight into the pinned host buffer (k_reduce)
+    // small clouds (<= 1024 points): assembly, block reduction, fixed-order final sum, suffix sum and counters in ONE
+    // launch whose last block writes the result to the device buffer and straight into the pinned host buffer (k_reduce);
+    // larger ones: the assembly, then k_final (one wave per entry) and k_finish as launches of their own
+    const int fuse = grid <= 4 ? 1 : 0;
     hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(kBlock), lds, ctx->stream, ctx->d_traj, ctx->d_px, ctx->d_py,
                        (int)ctx->P, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
                        ctx->cfg.safety_hor, ctx->cfg.weight_p, ctx->d_block_partials, ctx->d_nonfinite, ctx->d_out,
-                       ctx->d_ctl, ctx->nbatch, ctx->it_done, (int)kOutPartial, (int)kOutDoubles, ctx->d_ticket, ctx->h_out_dev);
+                       ctx->d_ctl, ctx->nbatch, ctx->it_done, (int)kOutPartial, (int)kOutDoubles, ctx->d_ticket, ctx->h_out_dev, fuse);
+    if (!fuse) {
+      hipLaunchKernelGGL(k_final, dim3((unsigned)plen), dim3(64), 0, ctx->stream, ctx->d_block_partials, (int)grid, ctx->d_sums);
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
+                         ctx->nbatch, ctx->it_done, ctx->d_nonfinite,
+                         reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial), ctx->h_out_dev, (int)kOutDoubles);
+    }
     host_written = ctx->h_out_dev != nullptr;
   } else {
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, kOutPartial * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_sums, N, ctx->d_out, ctx->d_ctl,
                        ctx->nbatch, ctx->it_done, ctx->d_nonfinite,
-                       reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial));
+                       reinterpret_cast<unsigned long long *>(ctx->d_out + kOutPartial), ctx->h_out_dev, (int)kOutDoubles);
+    host_written = ctx->h_out_dev != nullptr;
   }
   ctx->e_end = next_event(ctx);
   (void)hipEventRecord(ctx->ev_pool[ctx->e_end], ctx->stream);
