@@ -1487,21 +1487,46 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
   bool open = false;
   double cx = 0.0, cy = 0.0, r = 0.0, theta0 = 0.0, theta_res = 0.0;
     ia = (size_t)a;   // (a: compact interior index of the point; `start` is the batch's offset in the point arrays)
+    // Two memory round trips instead of five (round 5): the point's whole state in one go, then -- before anything is
+    // decided -- the point's coordinates and THIS LANE'S samples of the round that may have to be closed (solved value,
+    // time, angle, bound).  The old order (state -> phase -> sample count -> solved values -> arg-max -> its time and
+    // angle -> the bounds of the unsolved ones) was a chain of dependent loads, each a trip to L2 / HBM: a fifth of
+    // k_round's wave cycles in the lazy mode, ~ 40 us of a reference-scale callback.  Same values, same decisions.
     i = gs.pt[ia];
-    cx = px_[i]; cy = py_[i];
     r = gs.r[ia]; theta0 = gs.theta0[ia]; theta_res = gs.theta_res[ia];
-    open = gs.phase[ia] == kPhaseNew;
+    const int phase_ = gs.phase[ia];
+    const int n_pre = gs.nsamp[ia];
+    const unsigned req_pre = gs.req[ia];
+    const int iter_pre = gs.iter[ia];
+    cx = px_[i]; cy = py_[i];
+    const double rest_pre = res_t[i];
+    // (the sample prefetch only with 32 lanes per point -- one sample per lane: four registers; with 8 lanes and three
+    // samples per lane it costs 25 VGPRs and a wave per SIMD in exactly the launches that hold every interior point)
+    constexpr bool PRE = !SVSDF_LEAN_HANDOFF && LP == 32;
+    double g_pre[NP], t_pre[NP], th_pre[NP], ub_pre[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int j = l + LP * ps;
+      const size_t s_ = sample_slot(stride, ia, (j < kMaxSlots) ? j : 0);
+      const bool ld = PRE && j < kMaxSlots;
+      g_pre[ps] = ld ? gs.sq_sdf[s_] : kUnsolved;
+      t_pre[ps] = ld ? gs.sq_t[s_] : 0.0;
+      th_pre[ps] = ld ? gs.sqth[s_] : 0.0;
+      ub_pre[ps] = ld ? gs.sq_ub[s_] : 0.0;
+    }
+    open = phase_ == kPhaseNew;
     if (!open) {
       // ---- close the round: max over the solved samples, first index wins ties (strict >)
-      const int n = gs.nsamp[ia];
-      const unsigned req = gs.req[ia];   // samples requested so far: the solved ones
+      const int n = n_pre;
+      const unsigned req = req_pre;   // samples requested so far: the solved ones
       double g_mine[NP];
       double g = kUnsolved;
       int idx = 0x7fffffff;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        g_mine[ps] = (j < n && (!SVSDF_LEAN_HANDOFF || ((req >> j) & 1u))) ? gs.sq_sdf[sample_slot(stride, ia, j)] : kUnsolved;
+        if constexpr (PRE) g_mine[ps] = (j < n) ? g_pre[ps] : kUnsolved;
+        else g_mine[ps] = (j < n && (!SVSDF_LEAN_HANDOFF || ((req >> j) & 1u))) ? gs.sq_sdf[sample_slot(stride, ia, j)] : kUnsolved;
         if (g_mine[ps] > g || (g_mine[ps] == g && j < idx)) { g = g_mine[ps]; idx = j; }
       }
       {  // lexicographic (max g, min index) over the LP lanes: butterfly through DPP (Grp<LP>::xchg)
@@ -1514,17 +1539,29 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           step(Grp<LP>::template xchg<4>(g), Grp<LP>::template xchg<4>(idx));
         }
       }
-      double max_g = -100000, real_t = res_t[i], star_th = 0.0;
+      double max_g = -100000, real_t = rest_pre, star_th = 0.0;
       if (g > max_g) {
-        const size_t sb = sample_slot(stride, ia, idx);
-        max_g = g; real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
+        max_g = g;
+        if constexpr (!PRE) {
+          const size_t sb = sample_slot(stride, ia, idx);
+          real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
+        } else {
+          // the arg-max sample's time and angle: from the lane that holds it (pass idx / LP of lane idx % LP)
+          double tsel = t_pre[0], thsel = th_pre[0];
+#pragma unroll
+          for (int ps = 1; ps < NP; ++ps)
+            if (idx / LP == ps) { tsel = t_pre[ps]; thsel = th_pre[ps]; }
+          real_t = __shfl(tsel, idx % LP, LP);
+          star_th = __shfl(thsel, idx % LP, LP);
+        }
       }
       // unsolved samples that could still reach max_g -> supplementary solves
       bool any = false;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
         const int j = l + LP * ps;
-        list_me[ps] = (j < n) && (SVSDF_LEAN_HANDOFF ? !((req >> j) & 1u) : (g_mine[ps] == kUnsolved)) && gs.sq_ub[sample_slot(stride, ia, j)] >= max_g;
+        if constexpr (PRE) list_me[ps] = (j < n) && (g_mine[ps] == kUnsolved) && ub_pre[ps] >= max_g;
+        else list_me[ps] = (j < n) && (SVSDF_LEAN_HANDOFF ? !((req >> j) & 1u) : (g_mine[ps] == kUnsolved)) && gs.sq_ub[sample_slot(stride, ia, j)] >= max_g;
         mlist[ps] = ballot_g(list_me[ps]);
         any = any || (mlist[ps] != 0u);
       }
@@ -1555,7 +1592,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         if (l == 0) gs.phase[ia] = (int)kPhaseSupp;
       } else {
         const double r_star = r - max_g;
-        const int iter = gs.iter[ia];
+        const int iter = iter_pre;
         if (iter > 8 || fabs(max_g) < 0.1) {
           if (l == 0) {
             const double corx = cx + 1.0 * r_star * cos(star_th);
