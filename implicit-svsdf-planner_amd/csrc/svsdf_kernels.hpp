@@ -2155,7 +2155,9 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
 // ---------------------------------------------------------------------------------------------
 constexpr int kTailBlock = 256;
 constexpr int kTailFetch = 2;     // points a wave takes from the active list per atomic (8 made the last waves serialise four pairs each: + 1 ms beyond 6144 points)
-constexpr size_t kTailWaveLds = ((ladder_lds_bytes(2) + 15) & ~(size_t)15) + 2 * kMaxCand * sizeof(unsigned short) + 64 * sizeof(unsigned);
+// the wave's own copy of the GSIP state and samples of its two points (it0 == 0, see k_tail): 6 + 6 * 48 doubles, 10 + 48 ints
+constexpr size_t kTailLocalBytes = ((6 + 6 * 2 * kMaxSlots) * sizeof(double) + (10 + 2 * kMaxSlots) * sizeof(int) + 15) & ~(size_t)15;
+constexpr size_t kTailWaveLds = ((ladder_lds_bytes(2) + 15) & ~(size_t)15) + 2 * kMaxCand * sizeof(unsigned short) + 64 * sizeof(unsigned) + kTailLocalBytes;
 template <int SHAPE, int G>
 __device__ __forceinline__ void tail_solve_pass(const TrajL &tr, const double *__restrict__ tk, const ShapeParams &sp,
                                                 const Pose *pose, const Chunk *chunks, int K, int nch, const GsipState &gs,
@@ -2225,6 +2227,24 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   char *wave_lds = reinterpret_cast<char *>(tail_lds + ((tables + 1) & ~(size_t)1)) + (threadIdx.x >> 6) * kTailWaveLds;
   unsigned short *clist_w = reinterpret_cast<unsigned short *>(wave_lds + ((ladder_lds_bytes(2) + 15) & ~(size_t)15));
   unsigned *qlist = reinterpret_cast<unsigned *>(clist_w + 2 * kMaxCand);
+  // Round 5: when the WHOLE GSIP loop runs here (it0 == 0: every point arrives fresh from k_classify, no round open), the
+  // state and the samples of the wave's two points live in the wave's own LDS instead of the interior-sized arrays in
+  // global memory: round_point and the solve passes are handed a GsipState whose pointers address that LDS block (generic
+  // pointers; slot = sample * 2 + half), nothing else changes.  A GSIP step was four dependent trips to L2 (state,
+  // samples, the solve's inputs, its results) of ~ 1.5 us each around ~ 20 us of arithmetic, ten steps per point.
+  const bool local = it0 == 0 && (clist_on & 4) != 0;   // (bit 2 of clist_on: the host's switch, SVSDF_TAIL_LOCAL=0 turns it off)
+  GsipState gl = gs;
+  {
+    double *ld = reinterpret_cast<double *>(qlist + 64);
+    gl.r = ld; gl.theta0 = ld + 2; gl.theta_res = ld + 4;
+    gl.sqx = ld + 6; gl.sqy = gl.sqx + 2 * kMaxSlots; gl.sqth = gl.sqy + 2 * kMaxSlots; gl.sq_ub = gl.sqth + 2 * kMaxSlots;
+    gl.sq_sdf = gl.sq_ub + 2 * kMaxSlots; gl.sq_t = gl.sq_sdf + 2 * kMaxSlots;
+    int *li_ = reinterpret_cast<int *>(gl.sq_t + 2 * kMaxSlots);
+    gl.pt = li_; gl.iter = li_ + 2; gl.nsamp = li_ + 4; gl.phase = li_ + 6; gl.req = reinterpret_cast<unsigned *>(li_ + 8);
+    gl.sq_k = li_ + 10;
+  }
+  const GsipState ga = local ? gl : gs;
+  const size_t stride_a = local ? (size_t)2 : stride;
   const int start = ctl->start;
   const int *cur = gs.list[it0 & 1] + start;
   const int lane = (int)(threadIdx.x & 63);
@@ -2260,22 +2280,34 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
       }
       if (q_next < q_end) {
         const int e = q_next++;
-        if (h == hh) { a = cur[e]; steps = 0; own = false; }
+        if (h == hh) {
+          a = cur[e]; steps = 0; own = false;
+          if (local && l == 0) {   // the point's state as k_classify left it, into this half's slot of the wave's LDS copy
+            const size_t ia_ = (size_t)a;
+            gl.pt[h] = gs.pt[ia_]; gl.r[h] = gs.r[ia_]; gl.theta0[h] = gs.theta0[ia_]; gl.theta_res[h] = gs.theta_res[ia_];
+            gl.iter[h] = gs.iter[ia_]; gl.nsamp[h] = gs.nsamp[ia_]; gl.phase[h] = gs.phase[ia_]; gl.req[h] = 0u;
+          }
+        }
       }
     }
     if (__builtin_amdgcn_readlane(a, 0) < 0 && __builtin_amdgcn_readlane(a, 32) < 0) break;
+    if (local) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     // ---- one GSIP step per half: close / finish / open + select (k_round's round_point, 32 lanes per point)
     RoundOut<1> ro;
     ro.list_me[0] = false; ro.mlist[0] = 0u; ro.n_emit = 0; ro.push_next = false; ro.finished = false;
     if (a >= 0) {
       const double dl = (steps >= all_after) ? 1e300 : delta, bd = (steps >= all_after) ? 1e300 : band_delta;
-      round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, dl, bd, res_sdf, res_t, res_gx,
+      round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, ga, stride_a, start, local ? h : a, dl, bd, res_sdf, res_t, res_gx,
                                    res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc);
       ++steps;
       if (ro.n_emit > 0) own = true;
       if (l == 0) n_emit_tot += ro.n_emit;
     }
-    const size_t ia = (size_t)(a >= 0 ? a : 0);
+    const size_t ia = local ? (size_t)h : (size_t)(a >= 0 ? a : 0);
     if (ro.finished) a = -1;
     // ---- the wave's solve list: the selected samples of both halves
     const unsigned m_mine = (a >= 0) ? ro.mlist[0] : 0u;
@@ -2284,7 +2316,7 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     const int nq = n0 + n1;
     if ((m_mine >> l) & 1u) {
       const bool seeded = own ? (MODE != 0) : (prev_mode != 0);
-      qlist[(h ? n0 : 0) + __popc(m_mine & lt_mask)] = (unsigned)sample_slot(stride, ia, l) | (seeded ? 0x80000000u : 0u);
+      qlist[(h ? n0 : 0) + __popc(m_mine & lt_mask)] = (unsigned)sample_slot(stride_a, ia, l) | (seeded ? 0x80000000u : 0u);
     }
     // the samples and the point state just written are read by other lanes of this wave, the solved values below by the
     // next step's close
@@ -2293,12 +2325,12 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (nq > 0) {
       if (nq <= 2) {
-        tail_solve_pass<SHAPE, 32>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
+        tail_solve_pass<SHAPE, 32>(tr, tk, sp, pose, chunks, K, nch, ga, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
       } else if (nq <= 8) {
-        tail_solve_pass<SHAPE, 8>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
+        tail_solve_pass<SHAPE, 8>(tr, tk, sp, pose, chunks, K, nch, ga, qlist, 0, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
       } else {
         for (int base = 0; base < nq; base += 32)
-          tail_solve_pass<SHAPE, 2>(tr, tk, sp, pose, chunks, K, nch, gs, qlist, base, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
+          tail_solve_pass<SHAPE, 2>(tr, tk, sp, pose, chunks, K, nch, ga, qlist, base, nq, prune, wave_lds, n_eval, n_scan, n_solved, n_spec, sc);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();

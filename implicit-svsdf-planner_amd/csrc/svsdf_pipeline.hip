@@ -257,7 +257,7 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const TailLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it0, mode,
                      sel, ctx->select_delta, all_after, ppw, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                     ctx->d_ctl + b, ctx->round_list, ctx->prune};
+                     ctx->d_ctl + b, ctx->round_list | (ctx->tail_local ? 4 : 0), ctx->prune};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_tail(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a) && ctx->launch_err.empty())
@@ -750,10 +750,10 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   const int an_trial = (ctx->ub_env || ctx->saved_nbatch > 0) ? 0 : ctx->an_state;
   if (an_trial == 1) ctx->ub_anchor = false;
   if (an_trial == 2) ctx->ub_anchor = true;
-  // Batch count (large shards in the scanning modes; DESIGN.md "concurrent point batches").  Default: a RULE -- 3 batches in
-  // a scanning bound mode from 400 k points per device, 1 otherwise (what the measurements of rounds 3 - 4 -- 1 / 2 / 3 / 4 at NS, C3, C4 --
-  // chose on every box; with the main stream that is at most 4 streams, the HIP runtime's default number of hardware
-  // queues) -- so that the plan is the same on every run and settled after the deciding evaluation.  svsdf_set_plan
+  // Batch count (DESIGN.md "concurrent point batches").  Default: a RULE -- 3 batches from 80 k points per device, 1 below
+  // (round 5; rounds 3 - 4: from 400 k in a scanning mode only; what the measurements -- 1 / 2 / 3 / 4 at NS, C3, C4 and at
+  // 60 k ... 500 k points -- chose on every box; with the main stream that is at most 4 streams, the HIP runtime's default
+  // number of hardware queues) -- so that the plan is the same on every run and settled after the deciding evaluation.  svsdf_set_plan
   // (batches = -1) / SVSDF_BATCHES=measure ask for a measurement instead: after one evaluation that learns the launch
   // widths, every candidate count (1, 4 [2 in the lazy mode], 3) runs three evaluations, timed with HIP events on the
   // library's own stream (device time, not the host's wall clock), and the best median stays.  Every count computes the
@@ -812,7 +812,12 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_tune = 1;
     const bool big = ctx->ub_full && ctx->P >= 400000;
     if (ctx->want_batches == 0) {
-      const int nb = big ? 3 : 1;
+      // Round 5 (profiles/r05_batches_by_size.txt): 3 batches pay from ~ 80 k points per device in EVERY bound mode -- 60 k: + 2 ... 9 %,
+      // 100 k: + 9 ... 14 %, 150 - 250 k: + 4 ... 16 % (star / sdHorseshoe / sdHeart; 2 batches always in between, 4 lose at
+      // 500 k) -- not only from 400 k in the scanning modes (round 4's rule, measured at 1 M points only): the chain's ~ 20
+      // dependent launches leave the chip draining at every step, and another batch's kernels fill those tails whatever the
+      // bound mode.  Matters for BASELINE config 2 (100 k points) and for the stripes of a multi-GPU run (C4 / 8 = 500 k, NS / 8 = 125 k).
+      const int nb = (ctx->P >= 80000) ? 3 : 1;
       if (ctx->saved_nbatch > 0) ctx->saved_nbatch = nb;        // (serialised for profiling: takes effect when that ends)
       else if (nb != ctx->nbatch) rc = set_batches(ctx, nb);
     } else if (ctx->want_batches < 0 && big) {

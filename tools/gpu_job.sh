@@ -40,7 +40,7 @@ for STEP in "$@"; do
     bench)    timeout 900 python -u bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err ;;
     benchq)   timeout 300 python -u bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_quick.json 2> $OUT/${TAG}_bench_quick.err ;;
     benchv)   SVSDF_LIB_VARIANT=$ARG timeout 300 python -u bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_quick_$ARG.json 2> $OUT/${TAG}_bench_quick_$ARG.err ;;
-    abenv)    IFS=: read -r SPEC C P <<< "$ARG"; timeout 600 python -u tools/ab_env.py - "$SPEC" ${C:-C3,NS} ${P:-0} > $OUT/${TAG}_abenv.txt 2>&1 ;;
+    abenv)    IFS=: read -r SPEC C P <<< "$ARG"; timeout 600 python -u tools/ab_env.py - "$SPEC" ${C:-C3,NS} ${P:-0} > $OUT/${TAG}_abenv_$(echo ${C:-C3,NS} | tr ',' '_')_${P:-0}.txt 2>&1 ;;
     stripes8) timeout 600 python -u bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config C4 --steps 10 --no-extras > $OUT/${TAG}_stripes8.json 2> $OUT/${TAG}_stripes8.err ;;
     ab)       IFS=: read -r V C P <<< "$ARG"; timeout 900 python -u tools/exp_variants.py "$V" ${C:-C3,NS} ${P:-1000000} > $OUT/${TAG}_ab_$(echo $V | tr ',' '_')_$(echo ${C:-C3,NS} | tr ',' '_').txt 2>&1 ;;
     pytest)   if [ -n "$ARG" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$ARG" > $OUT/${TAG}_pytest.txt 2>&1; else timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_pytest.txt 2>&1; fi; tail -3 $OUT/${TAG}_pytest.txt ;;
