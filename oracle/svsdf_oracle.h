@@ -57,7 +57,7 @@ enum {
   ORC_SHAPE_COUNT = 17
 };
 
-#define ORC_MAX_POLY_VERTS 4096
+#define ORC_MAX_POLY_VERTS 8192
 
 typedef struct orc_shape {
   int id;

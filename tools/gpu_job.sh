@@ -43,7 +43,7 @@ for STEP in "$@"; do
     abenv)    IFS=: read -r SPEC C P <<< "$ARG"; timeout 600 python -u tools/ab_env.py - "$SPEC" ${C:-C3,NS} ${P:-0} > $OUT/${TAG}_abenv_$(echo ${C:-C3,NS} | tr ',' '_')_${P:-0}.txt 2>&1 ;;
     stripes8) timeout 600 python -u bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config C4 --steps 10 --no-extras > $OUT/${TAG}_stripes8.json 2> $OUT/${TAG}_stripes8.err ;;
     ab)       IFS=: read -r V C P <<< "$ARG"; timeout 900 python -u tools/exp_variants.py "$V" ${C:-C3,NS} ${P:-1000000} > $OUT/${TAG}_ab_$(echo $V | tr ',' '_')_$(echo ${C:-C3,NS} | tr ',' '_').txt 2>&1 ;;
-    pytest)   if [ -n "$ARG" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$ARG" > $OUT/${TAG}_pytest.txt 2>&1; else timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_pytest.txt 2>&1; fi; tail -3 $OUT/${TAG}_pytest.txt ;;
+    pytest)   if [ -n "$ARG" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$ARG" > $OUT/${TAG}_pytest.txt 2>&1; else timeout 1500 python -m pytest tests -x -q -m gpu --durations=20 > $OUT/${TAG}_pytest.txt 2>&1; fi; tail -3 $OUT/${TAG}_pytest.txt ;;
     fuzz)     IFS=: read -r N S <<< "$ARG"; timeout 900 python -u tools/fuzz_parity.py ${N:-100} ${S:-1} > $OUT/${TAG}_fuzz_${S:-1}.txt 2>&1 ;;
     kt)
       (cd /tmp && rm -rf /tmp/kt_$TAG && SVSDF_BATCHES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python -u $ROOT/bench.py --config $ARG --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_kt_$ARG.log 2>&1
