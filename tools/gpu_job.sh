@@ -17,6 +17,7 @@
 #   kt:<config>  rocprofv3 --kernel-trace --stats of the bench command on one config, one batch (SVSDF_BATCHES=1) + timeline
 #   pmc:<config> separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*) of the same command -> tools/pmc_summary.py
 #   pmcref[:<map>]  PMC passes (instruction mix, wave cycles, instruction cache) of reference-scale callbacks
+#   profround:<config>   tools/profile_round.sh: bench line + kernel stats + separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ_*) + one-batch trace
 #   smoke        __graft_entry__.smoke()
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -63,6 +64,7 @@ for STEP in "$@"; do
          timeout 200 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $D -o p -- python -u $ROOT/tools/ref_trace.py ${ARG:-star} 12 > /tmp/pmcref.log 2>&1 || tail -3 /tmp/pmcref.log
        done
        python $ROOT/tools/pmc_agg.py $(find /tmp/pmcref_${TAG}_* -name '*counter_collection.csv') > $OUT/${TAG}_pmcref_${ARG:-star}.txt 2>&1) ;;
+    profround) bash tools/profile_round.sh ${TAG} ${ARG:-C3} > /dev/null 2>&1 ;;
     smoke)    timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.txt 2>&1; tail -2 $OUT/${TAG}_smoke.txt ;;
     *) echo "unknown step $STEP" ;;
   esac
