@@ -613,7 +613,7 @@ void svsdf_backward_T(const double *T, double *tau, int N) {
 static int lmbm_prepare(svsdf_ctx *ctx, const double *x, int n) {
   if (!ctx || !x || n < 1 || (n + 3) % 4 != 0) return fail(ctx, SVSDF_ERR_INVALID, "n must be 4N - 3");
   const int N = (n + 3) / 4;
-  if (N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N > 64");
+  if (N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N > 128");
   ctx->xlast.assign(x, x + n);
   ctx->T.resize(N);
   for (int i = 0; i < N; ++i) ctx->T[i] = svsdf_host::tau_to_T(x[i]);  // forwardT

@@ -36,7 +36,7 @@ namespace svsdf {
 #ifndef SVSDF_FUSED_PASS
 #define SVSDF_FUSED_PASS 1   // a wave's LAST open descent: derivative + both signs of the ladder in one step (descend_from_seed)
 #endif
-constexpr int kMaxPieces = 64;
+constexpr int kMaxPieces = 128;   // = SVSDF_MAX_PIECES (64 until round 5); sizes TrajDev and the result rows, nothing on the hot path
 constexpr int kMaxSlots = 24;   // GSIP samples per round: 2, 6, 18, 21, 21, ... (SWM:60-71,105-110)
 constexpr int kMaxRounds = 9;   // SWM:995 (iter > 8)
 constexpr int kBlock = 256;
@@ -2572,7 +2572,15 @@ __device__ __forceinline__ void finish_body(const double *__restrict__ sums, int
   }
 }
 
-// (host_out / out_doubles: the pinned host buffer the whole result -- partial + counters, laid out like `partial` -- is also
+// What the host reads of a result row [sums (19 kMaxPieces + 1) | counters]: the 19 N + 1 sums in use and the counters.
+__device__ __forceinline__ void copy_result_to_host(double *__restrict__ host_out, const double *__restrict__ out, int N,
+                                                    int out_partial, int out_doubles) {
+  const int plen = 19 * N + 1;
+  for (int k = threadIdx.x; k < plen; k += blockDim.x) host_out[k] = out[k];
+  for (int k = out_partial + threadIdx.x; k < out_doubles; k += blockDim.x) host_out[k] = out[k];
+}
+
+// (host_out / out_doubles: the pinned host buffer the result -- partial + counters, laid out like `partial` -- is also
 // written to, or null)
 __global__ void k_finish(const double *__restrict__ sums, int N, double *__restrict__ partial,
                          const BatchCtl *__restrict__ ctl, int nbatch, int it_end,
@@ -2582,7 +2590,7 @@ __global__ void k_finish(const double *__restrict__ sums, int N, double *__restr
   if (host_out) {
     __threadfence();
     __syncthreads();
-    for (int k = threadIdx.x; k < out_doubles; k += blockDim.x) host_out[k] = partial[k];
+    copy_result_to_host(host_out, partial, N, (int)(reinterpret_cast<const double *>(stats_out) - partial), out_doubles);
   }
 }
 
@@ -2640,8 +2648,7 @@ k_reduce(const TrajDev *__restrict__ trg, const double *__restrict__ px_, const 
   finish_body(sums, N, out, ctl, nbatch, it_end, nonfinite, reinterpret_cast<unsigned long long *>(out + out_partial));
   __threadfence();
   __syncthreads();
-  if (host_out)
-    for (int k = threadIdx.x; k < out_doubles; k += blockDim.x) host_out[k] = out[k];
+  if (host_out) copy_result_to_host(host_out, out, N, out_partial, out_doubles);
   if (threadIdx.x == 0 && !one_block) *ticket = 0u;
 }
 

@@ -298,7 +298,7 @@ void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
 // Upload (coeffs, T), update traj_duration like SweptVolumeManager::updateTraj (SWM:376-385),
 // build the layer-1 time grid exactly like the reference's accumulating loop (SWM:567).
 int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bool clear_nonfinite = false) {
-  if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 64]");
+  if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 128]");
   double td = 0.0;
   for (int i = 0; i < N; ++i) td += T[i];  // Trajectory::getTotalDuration (TRJ:410-419)
   if (!(td == td) || std::isinf(td)) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite duration");
@@ -713,7 +713,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     // an obstacle-free window (or an empty stripe): the reference's loop over parallel_points_num == 0 adds
     // nothing (BEO:785) and the callback returns energy + rho * sum(T).  The trajectory is still validated and
     // traj_duration updated (SWM:376-385); the partial is zero on the host and on the device (collectives).
-    if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 64]");
+    if (N < 1 || N > kMaxPieces) return fail(ctx, SVSDF_ERR_INVALID, "N out of range [1, 128]");
     double td = 0.0;
     for (int i = 0; i < N; ++i) {
       if (!std::isfinite(T[i])) return fail(ctx, SVSDF_ERR_NONFINITE, "non-finite duration");

@@ -50,7 +50,10 @@ enum svsdf_shape_id {
   SVSDF_SHAPE_COUNT = 17
 };
 
-#define SVSDF_MAX_PIECES 64        /* MINCO pieces per trajectory handled on the device */
+#define SVSDF_MAX_PIECES 128       /* MINCO pieces per trajectory handled on the device (64 until round 5).  The reference has no
+                                      cap (minco.hpp:433-513); what bounds a trajectory here beyond this is the LDS pose table: one pose
+                                      per 0.15 s of duration (SWM:567), ~ 36 B each, in one block's share of the CU's 160 KB --
+                                      SVSDF_ERR_INVALID "trajectory too long for the LDS pose table" otherwise */
 #define SVSDF_MAX_POLY_VERTS 8190  /* Polygon outline vertices + one per loop of a multi-loop outline (the z = 0 outlines of
                                       the reference meshes have 77 ... 754) */
 #define SVSDF_MAX_DEVICES 8        /* GPUs one context can drive (one xGMI node) */

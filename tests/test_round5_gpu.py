@@ -221,3 +221,44 @@ def test_batches_rule_and_clock(built):
         assert st["batches"] == nb and c.get_plan()["batches"] == nb, (P, st["batches"])
         assert 800.0 < st["shader_clock_mhz"] < 3500.0, st["shader_clock_mhz"]
         c.close()
+
+
+@pytest.mark.parametrize("N,piece_s", [(65, 1.7), (96, 1.2), (128, 0.9)])
+def test_more_than_64_pieces(built, N, piece_s):
+    """SVSDF_MAX_PIECES is 128 since round 5 (64 before; the reference has no cap, minco.hpp:433-513): trajectories of 65 /
+    96 / 128 pieces with generic durations -- the penalty, every per-point result and the full optimizer callback (host MINCO
+    forward + adjoint at that N) against the oracle; one piece more than the cap is refused with SVSDF_ERR_INVALID."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    w = workload.make("C3", P=4000, N=N)
+    rng = np.random.default_rng(N)
+    w["T"] = piece_s * (1.0 + 1e-3 * rng.standard_normal(N))
+    w["coeffs"] = svsdf_amd.minco_coeffs(w["head_state"], w["tail_state"], w["q"], w["T"])
+    c = _ctx(w)
+    c.set_points(w["points"])
+    o = _oracle(w)
+    o.set_traj(w["coeffs"], w["T"])
+    ocost, ogT, ogC, osdf, ots, _ = o.penalty(w["points"], nthreads=NT, sum_mode=1, per_point=True)
+    for _ in range(3):
+        cost, gT, gC = c.eval_penalty(w["coeffs"], w["T"])
+    sdf, ts, g, _ = c.query_points(w["coeffs"], w["T"])
+    assert ocost > 0 and int((osdf <= 0).sum()) > 50
+    flips = np.abs(ts - ots) > 1e-6
+    assert flips.mean() <= 5e-3, int(flips.sum())
+    assert np.abs(sdf[~flips] - osdf[~flips]).max() <= 1e-7
+    assert abs(cost - ocost) <= 1e-7 * abs(ocost), (cost, ocost)
+    assert _rel(gC, ogC) <= 1e-5 and _rel(gT, ogT) <= 1e-5, (_rel(gC, ogC), _rel(gT, ogT))
+    x = workload.x_from(w["q"], w["T"], svsdf_amd.backward_T)
+    f, gx = c.lmbm_evaluate(x)
+    fo, go, c3 = o.cost_function(w["points"], x, nthreads=NT)
+    assert abs(f - fo) <= 1e-7 * abs(fo), (f, fo)
+    assert _rel(gx, go) <= 1e-5, _rel(gx, go)
+    if N == 128:
+        w2 = workload.make("C3", P=100, N=129)
+        T2 = np.full(129, 0.9)
+        co2 = svsdf_amd.minco_coeffs(w2["head_state"], w2["tail_state"], w2["q"], T2)
+        with pytest.raises(Exception):
+            c.eval_penalty(co2, T2)
+        cost3, _, _ = c.eval_penalty(w["coeffs"], w["T"])      # the context is still usable
+        assert cost3 == cost
+    c.close()
