@@ -28,6 +28,7 @@ Workloads (svsdf_amd/workload.py, BASELINE.json `configs`):
 Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -573,11 +574,15 @@ def sustained(r, steps=300, seed=11):
     return {"steps": steps, "seconds": total, "ms_per_step": 1e3 * total / steps, "value": r.P_total * steps / total,
             "unit": "query-points/s", "first_%d_ms" % h: float(per[:h].mean()), "last_%d_ms" % h: float(per[-h:].mean()),
             "last_over_first": float(per[-h:].mean() / per[:h].mean()), "median_ms": float(np.median(per)),
-            "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
+            "first_%d_median_ms" % h: float(np.median(per[:h])), "last_%d_median_ms" % h: float(np.median(per[-h:])),
+            "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()), "max_step": int(per.argmax()),
+            "steps_over_1p5_median": int((per > 1.5 * np.median(per)).sum()),
             "shader_clock_mhz_first": float(clk[:h].mean()), "shader_clock_mhz_last": float(clk[-h:].mean()),
             "shader_clock_mhz_min": float(clk.min()), "piece_time_exact": r.ctx.stats()["piece_time_exact"],
             "note": "generic piece durations (the production regime); shader clock = s_memtime cycles per s_memrealtime "
-                    "cycle over the life of the main solve's first wave, read by the kernel itself"}
+                    "cycle over the life of the main solve's first wave, read by the kernel itself; the interpreter's objects "
+                    "are frozen out of the cyclic collector (main(): gc.freeze) -- until then a full collection over "
+                    "torch's ~ 1e6 objects put one 35 ms pause at a random step (profiles/r05_stall_probe.txt)"}
 
 
 def stripe_report(r, devices, steps=3):
@@ -635,6 +640,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # The interpreter's cyclic collector: with torch imported a full collection walks ~ 1e6 objects -- one 35 ms pause every
+    # few hundred evaluations, i.e. inside a timed region now and then (tools/stall_probe.py: the same loop on the bare
+    # context has none in 1 500 steps).  Everything alive now is moved to the permanent generation; later collections only
+    # see what the loops allocate.  (The reference's host is C++.)
+    gc.collect()
+    gc.freeze()
     if a.only == "reference_scale":
         print(json.dumps({"reference_scale": reference_scale(local_rank)}), flush=True)
         return
