@@ -165,7 +165,7 @@ class Runner:
                 "first_evaluation_ms": first_ms, "settle_evaluations": n, "batches": st["batches"],
                 "gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan", "anchor-scan"][st["gsip_bound_mode"]],
                 "bound_ratio": st["bound_ratio"], "rule": "deterministic, from the first evaluation's counters: GSIP solves / "
-                "samples > 0.5 (Polygon 0.2) -> full-scan; else lazy-scan from 400 k points per device, cheap-chunk below; "
+                "samples > 0.5 (Polygon 0.2) -> full-scan; else lazy-scan from 400 k points per device, cheap-chunk below (a cloud small enough for the fused tail tries lazy-scan once and keeps it when it saves a quarter of the GSIP solves); "
                 "batches: 1 / 3 / 4 timed once each on a large shard in a scanning mode, fastest kept"}
 
     def timed(self, steps, warmup):

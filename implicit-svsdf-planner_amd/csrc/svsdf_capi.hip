@@ -503,7 +503,7 @@ int svsdf_get_plan(const svsdf_ctx *ctx, svsdf_plan *out) {
   out->batches = (c->saved_nbatch > 0) ? c->saved_nbatch : c->nbatch;
   out->lanes_per_query = c->G;
   out->tail_iter = (c->tail_mode == -2) ? -2 : (c->tail_mode >= 0) ? c->tail_mode : (c->have_prev_nactive ? choose_tail_iter(c) : SVSDF_PLAN_AUTO);
-  out->settled = ((c->ub_env || c->ub_tune > 0) && c->bt_state == 0 && c->an_state == 0 && c->have_prev_nsolve) ? 1 : 0;
+  out->settled = ((c->ub_env || c->ub_tune > 0) && c->bt_state == 0 && c->an_state == 0 && c->lz_state == 0 && c->have_prev_nsolve) ? 1 : 0;
   return SVSDF_OK;
 }
 
@@ -526,7 +526,7 @@ int svsdf_set_plan(svsdf_ctx *ctx, const svsdf_plan *plan) {
   } else {
     const bool full = plan->bound_mode != 0, lazy = plan->bound_mode == 2, anchor = plan->bound_mode == 3;
     if (!ctx->ub_env || full != ctx->ub_full || lazy != ctx->ub_lazy || anchor != ctx->ub_anchor) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; ctx->ub_tune = 0; }
-    ctx->ub_env = true; ctx->ub_full = full; ctx->ub_lazy = lazy; ctx->ub_anchor = anchor; ctx->an_state = 0;
+    ctx->ub_env = true; ctx->ub_full = full; ctx->ub_lazy = lazy; ctx->ub_anchor = anchor; ctx->an_state = 0; ctx->lz_state = 0;
   }
   ctx->want_batches = (plan->batches == SVSDF_PLAN_AUTO) ? 0 : (plan->batches == -2) ? -1 : plan->batches;
   ctx->bt_state = 0;

@@ -127,6 +127,8 @@ struct svsdf_ctx {
   bool ub_anchor = false;      // with ub_full && !ub_lazy: anchor scans (k_round MODE 3: every third sample, the rest by their Lipschitz bound)
   int an_state = 0;            // anchor trial: 0 decided / idle, 1 next evaluation counts the full mode's table evaluations, 2 the anchor mode's
   unsigned long long an_full_evals = 0;
+  int lz_state = 0;            // lazy-scan trial of a small cloud: 0 idle, 1 the next evaluation runs in the lazy mode and is judged by its GSIP solves
+  unsigned long long lz_cheap_solves = 0;
   bool ub_env = false;         // env SVSDF_UB_FULL=0/1/2 pins the mode, otherwise run_pipeline decides after one evaluation
   int ub_tune = 0;             // evaluations since the point set changed that took part in the decision (0 or 1)
   double ub_ratio = 0.0;       // GSIP solves / GSIP samples of the deciding (cheap-bound) evaluation

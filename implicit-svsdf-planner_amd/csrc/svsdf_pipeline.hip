@@ -697,7 +697,7 @@ void fill_mode_stats(svsdf_ctx *ctx) {
   ctx->stats.gsip_bound_mode = bound_mode_of(ctx);
   ctx->stats.piece_time_exact = ctx->stats_piece_time;
   ctx->stats.bound_mode_decided = (ctx->ub_env || ctx->ub_tune > 0) ? 1 : 0;
-  ctx->stats.plan_settled = (ctx->stats.bound_mode_decided && ctx->bt_state == 0 && ctx->an_state == 0 && ctx->have_prev_nsolve) ? 1 : 0;
+  ctx->stats.plan_settled = (ctx->stats.bound_mode_decided && ctx->bt_state == 0 && ctx->an_state == 0 && ctx->lz_state == 0 && ctx->have_prev_nsolve) ? 1 : 0;
   ctx->stats.bound_ratio = ctx->ub_ratio;
   ctx->stats.n_devices = 1;
   ctx->stats.combine = SVSDF_COMBINE_HOST;
@@ -742,7 +742,7 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   // evaluations per mode with the wall clock; the rule reproduces its choices on C1-C5 without the five extra
   // evaluations and without depending on the box.)
   const bool deciding = !ctx->ub_env && ctx->ub_tune == 0;
-  if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; ctx->ub_anchor = false; ctx->an_state = 0; }
+  if (deciding) { ctx->ub_full = false; ctx->ub_lazy = false; ctx->ub_anchor = false; ctx->an_state = 0; ctx->lz_state = 0; }
   // Anchor trial (full-scan shapes only): one evaluation in the full mode and one in the anchor mode, compared by their
   // table-evaluation COUNTERS (deterministic: no timing) -- the anchor mode stays when it saves at least 28 % of them
   // (sdHeart - 32 %: k_round - 27 %, evaluation - 12 %; Polygon - 25 %: a wash; sdHorseshoe - 10 %: + 5 %, its extra passes
@@ -750,6 +750,10 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
   const int an_trial = (ctx->ub_env || ctx->saved_nbatch > 0) ? 0 : ctx->an_state;
   if (an_trial == 1) ctx->ub_anchor = false;
   if (an_trial == 2) ctx->ub_anchor = true;
+  // Lazy trial (round 5; small clouds of a cheap-bound shape only, see the deciding block below): this evaluation runs in
+  // the lazy mode and is judged by its GSIP solve COUNT against the cheap bound's (deterministic, no timing).
+  const int lz_trial = (ctx->ub_env || ctx->saved_nbatch > 0) ? 0 : ctx->lz_state;
+  if (lz_trial == 1) { ctx->ub_full = true; ctx->ub_lazy = true; }
   // Batch count (DESIGN.md "concurrent point batches").  Default: a RULE -- 3 batches from 80 k points per device, 1 below
   // (round 5; rounds 3 - 4: from 400 k in a scanning mode only; what the measurements -- 1 / 2 / 3 / 4 at NS, C3, C4 and at
   // 60 k ... 500 k points -- chose on every box; with the main stream that is at most 4 streams, the HIP runtime's default
@@ -792,6 +796,14 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     ctx->ub_anchor = keep;
     ctx->an_state = 0;
   }
+  if (lz_trial == 1) {
+    const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
+    const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
+    const bool keep = rc == SVSDF_OK && (double)gs <= 0.76 * (double)ctx->lz_cheap_solves;
+    if (!keep) { ctx->ub_full = false; ctx->ub_lazy = false; }
+    ctx->have_prev_nsolve = false;   // (the widths on record belong to the deciding evaluation / to the rejected mode; the interior count stands)
+    ctx->lz_state = 0;
+  }
   if (rc == SVSDF_OK && deciding) {
     const unsigned long long main_solves = ctx->stats.points - ctx->stats.culled_points;
     const unsigned long long gs = ctx->stats.solves > main_solves ? ctx->stats.solves - main_solves : 0ull;
@@ -804,6 +816,17 @@ int run_pipeline_leaf(svsdf_ctx *ctx, int N, const double *coeffs, const double 
     const bool large = ctx->P >= 400000;
     ctx->ub_full = ctx->ub_ratio > thr || large;
     ctx->ub_lazy = !(ctx->ub_ratio > thr);
+    // A SMALL cloud of a cheap-bound shape (round 5): when the fused tail owns the whole GSIP loop (choose_tail_iter: at most
+    // 24 interior points per CU) an evaluation is a latency chain -- a scan costs lanes that idle anyway, every solve it
+    // saves is a dozen dependent steps.  Whether the lazy scans save enough depends on the workload, not on the ratio above
+    // (star: 16 pieces / 1 k - 10 k points - 8 ... - 20 %, the reference's star map 398 -> 367 us; 8 pieces / 10 k points
+    // + 15 %: profiles/r05_small_cloud_modes.txt), so the next evaluation TRIES the lazy mode and stays in it when its GSIP
+    // solves drop to <= 76 % of this evaluation's (the cases above: 68 - 72 % against 83 - 87 %).  Same bits in every mode.
+    const long long tail_below = ctx->tail_below > 0 ? ctx->tail_below : (long long)ctx->n_cu * 24;
+    if (!ctx->ub_full && ctx->tail_mode != -2 && (long long)ctx->stats.interior_points <= tail_below && gs > 0) {
+      ctx->lz_state = 1;
+      ctx->lz_cheap_solves = gs;
+    }
     if (ctx->ub_full && !ctx->ub_lazy && ctx->lipschitz_ok) ctx->an_state = 1;   // full scans pay: does the anchor variant pay more?
     if (ctx->ub_full) { ctx->have_prev_nsolve = false; ctx->have_prev_nactive = false; }   // the launch plan on record is the cheap-bound one
   }
@@ -1097,6 +1120,7 @@ int take_stripe(svsdf_ctx *ctx, svsdf_ctx *planner, const CloudPlan &plan, int r
   ctx->ub_ratio = 0.0;
   if (!ctx->ub_env) { ctx->ub_full = false; ctx->ub_lazy = false; ctx->ub_anchor = false; }
   ctx->an_state = 0;
+  ctx->lz_state = 0;
   if (!ctx->G_env) {
     // (Polygon: 4 -- its 2-lane kernel spills 52 registers under the 3-waves cap; C5 36.5 vs 34.8 ms)
     ctx->G = default_lanes(ctx, Ps);

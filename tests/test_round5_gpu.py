@@ -262,3 +262,38 @@ def test_more_than_64_pieces(built, N, piece_s):
         cost3, _, _ = c.eval_penalty(w["coeffs"], w["T"])      # the context is still usable
         assert cost3 == cost
     c.close()
+
+
+def test_small_cloud_lazy_trial(built):
+    """Round 5: a small cloud (the fused tail owns the GSIP loop) of a cheap-bound shape TRIES the lazy scans in its second
+    evaluation and keeps them when they save a quarter of the GSIP solves -- decided by counters, so two contexts agree, the
+    plan settles within four evaluations, and no bit of the result depends on it.  16 pieces: kept; 8 pieces (C1): not."""
+    import svsdf_amd
+    from svsdf_amd import workload
+    for config, P, want in (("C2", 3000, 2), ("C1", 5000, 0)):
+        w = workload.make(config, P=P, minco=svsdf_amd.minco_coeffs)
+        plans, vals = [], []
+        for _ in range(2):
+            c = _ctx(w)
+            c.set_points(w["points"])
+            n = 0
+            first = None
+            while n < 8 and not c.get_plan()["settled"]:
+                out = c.eval_penalty(w["coeffs"], w["T"])
+                if first is None:
+                    first = out
+                assert out[0] == first[0] and np.array_equal(out[2], first[2]), (config, n)   # trial and final mode: same bits
+                n += 1
+            assert n <= 4, n
+            plans.append((c.get_plan(), n))
+            vals.append(c.eval_penalty(w["coeffs"], w["T"]))
+            assert c.stats()["tail_iter"] == 0
+            c.close()
+        assert plans[0] == plans[1], plans
+        assert plans[0][0]["bound_mode"] == want, (config, plans[0])
+        p = _ctx(w)
+        p.set_points(w["points"])
+        p.set_plan(bound_mode=0)
+        ref = p.eval_penalty(w["coeffs"], w["T"])
+        assert ref[0] == vals[0][0] and np.array_equal(ref[1], vals[0][1]) and np.array_equal(ref[2], vals[0][2])
+        p.close()
