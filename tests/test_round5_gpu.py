@@ -270,7 +270,7 @@ def test_small_cloud_lazy_trial(built):
     plan settles within four evaluations, and no bit of the result depends on it.  16 pieces: kept; 8 pieces (C1): not."""
     import svsdf_amd
     from svsdf_amd import workload
-    for config, P, want in (("C2", 3000, 2), ("C1", 5000, 0)):
+    for config, P, want in (("C2", 3000, 2), ("C1", 10000, 0)):   # (C1 at its BASELINE size: 86 % of the solves left -> rejected)
         w = workload.make(config, P=P, minco=svsdf_amd.minco_coeffs)
         plans, vals = [], []
         for _ in range(2):
