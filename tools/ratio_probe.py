@@ -1,5 +1,7 @@
+"""Round 5: the counters the GSIP bound-mode rule looks at after the FIRST evaluation of a point set (interior points, GSIP samples,
+solves, bound_ratio = GSIP solves / samples) on small clouds of every BASELINE config.  usage: ratio_probe.py"""
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "implicit-svsdf-planner_amd")]
 import numpy as np, svsdf_amd
 from svsdf_amd import workload
@@ -15,10 +17,3 @@ def run(w, tag):
 for cfg in ("C1", "C2", "NS", "C3", "C4"):
     for P in (300, 1000, 3000, 10000):
         run(workload.make(cfg, P=P, minco=svsdf_amd.minco_coeffs), cfg)
-for name in ("star", "sdHorseshoe", "sdHeart"):
-    rc = workload.reference_case(name)
-    w = rc["workload"] if "workload" in rc else rc
-    try:
-        run(dict(w, coeffs=rc["iterates"][0]["coeffs"], T=rc["iterates"][0]["T"]) if "iterates" in rc else w, "ref:" + name)
-    except Exception as ex:
-        print("ref", name, "skipped:", ex, list(rc.keys())[:12])
