@@ -515,7 +515,7 @@ def reference_scale(local_rank, calls=200, pieces=24, oracle_reps=5):
                 "interior_points": int(st["interior_points"]), "culled_points": int(st["culled_points"]),
                 "callback_us_median": float(np.median(per)), "callback_us_p10": float(np.percentile(per, 10)),
                 "callback_us_p90": float(np.percentile(per, 90)), "callback_us_mean": float(per.mean()),
-                "callbacks_per_s": calls / wall, "device_us": dev_us, "one_launch": int(st.get("small_path", 0)),
+                "callbacks_per_s": calls / wall, "device_us": dev_us,
                 "piece_time_exact": int(st["piece_time_exact"]), "shader_clock_mhz": st.get("shader_clock_mhz", 0.0),
                 "plan": {"gsip_bound_mode": ["cheap-chunk", "full-scan", "lazy-scan", "anchor-scan"][pl["bound_mode"]],
                          "batches": pl["batches"], "lanes_per_query": pl["lanes_per_query"], "tail_iter": st["tail_iter"]}}
@@ -729,9 +729,11 @@ def main():
     fp64 = fp64_accounting(acc, a.steps, solve_ms_step, r.solve_ms_serial, r.round_ms, r.round_ms_serial, ms_per_step,
                            ndev=(n_gpus if a.inprocess and multi else 1))
     traffic = None
+    traffic_total = None
     try:  # PMC-derived HBM traffic of k_solve per evaluation (collected offline, see profiles/)
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         traffic = tr.get(f"{name}:{a.dist}:{int(pts_dev)}")
+        traffic_total = tr.get(f"{name}:{a.dist}:{int(pts_dev)}:total")
     except Exception:
         pass
     if multi:
@@ -764,7 +766,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_solve (argmin over t: pruned table scan + scan layers 2-4 + descent; all launches of one evaluation)",
                      "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                      "traffic": traffic,
-                     "traffic_unit": "bytes per evaluation (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                     "traffic_total": traffic_total,
+                     "traffic_unit": "bytes per evaluation (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes); `traffic` = the dominant "
+                                     "kernel k_solve alone, `traffic_total` = every kernel of the evaluation (k_prep ... k_finish; most of it is "
+                                     "k_round's hand-off of GSIP samples through HBM)",
                      "kernel_ms_per_step": solve_ms_step, "kernel_ms_sum_per_step": r.solve_ms_sum,
                      "kernel_time_note": "a large shard runs as several point batches on concurrent streams (setup.batches): kernel_ms_per_step = time "
                                          "during which at least one k_solve launch was executing (merged HIP-event intervals; "

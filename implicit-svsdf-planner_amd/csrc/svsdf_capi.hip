@@ -251,10 +251,13 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
       return bail("shape bound kernel failed");
     const double rb = rbl[0];
     ctx->r_bound_sampled = rb;
-    // 1-Lipschitz self-check of the shape SDF (k_rbound): the value-based second cull and the anchor bound mode are exact
-    // only for such a function; a shape that fails (none of the 17 does) runs without both
+    // 1-Lipschitz check of the shape SDF (k_rbound): the value-based second cull and the anchor bound mode are exact
+    // only for such a function; a shape that fails (none of the 17 does) runs without both.  It is a SAMPLED
+    // sanity check (every node of a polar grid against four neighbours), not a proof: what makes the property true is
+    // that all 17 shapes are exact distance functions (tools/experiments/shape_lipschitz_check.py is the denser CPU study).
     ctx->lipschitz_excess = rbl[1];
-    if (rbl[1] > 0.0 || std::getenv("SVSDF_ASSUME_NOT_LIPSCHITZ")) { ctx->lipschitz_ok = false; ctx->cull2 = false; }
+    const char *nl = std::getenv("SVSDF_ASSUME_NOT_LIPSCHITZ");   // (test switch; "0" leaves the check's verdict alone)
+    if (rbl[1] > 0.0 || (nl && std::atoi(nl) != 0)) { ctx->lipschitz_ok = false; ctx->cull2 = false; }
     if (rb > analytic)
       return bail("svsdf_create: sampled shape bound " + std::to_string(rb) + " exceeds the analytic circumradius " +
                   std::to_string(analytic) + " (internal error: the pruning bound would be unsafe)");
@@ -430,15 +433,15 @@ long long svsdf_debug_sincos_mismatches(svsdf_ctx *ctx, double lo, double hi, in
 
 #ifdef SVSDF_SITE_STATS
 // diagnostic builds only (tools/site_stats.py): k_solve's per-site execution / lane counters of the last evaluation
-int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[20]) {
+int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[26]) {
   if (!ctx || ctx->host_only || !ctx->subs.empty()) return SVSDF_ERR_INVALID;
   if (hipSetDevice(ctx->device) != hipSuccess) return SVSDF_ERR_HIP_BASE;
   std::vector<BatchCtl> hc(kMaxBatches);
   if (hipMemcpy(hc.data(), ctx->d_ctl, sizeof(BatchCtl) * kMaxBatches, hipMemcpyDeviceToHost) != hipSuccess) return SVSDF_ERR_HIP_BASE;
-  for (int i = 0; i < 20; ++i) out[i] = 0;
+  for (int i = 0; i < 26; ++i) out[i] = 0;
   for (const BatchCtl &b : hc)
     for (const StatSlot &sl : b.stat)
-      for (int i = 0; i < 20; ++i) out[i] += sl.pad[i];
+      for (int i = 0; i < 26; ++i) out[i] += sl.pad[i];
   return SVSDF_OK;
 }
 #endif

@@ -265,6 +265,10 @@ inline int default_lanes(const svsdf_ctx *ctx, size_t Ps) {
 // queues down with the last stream, so the second generation of streams overlaps differently.  Pooled streams are created
 // once per device in a fixed order and never destroyed: every context that is alone on its device gets set 0, i.e. the
 // stream-to-queue mapping of a fresh process.
+// Limits: (a) the "fresh process" mapping holds for a context that is ALONE on its device -- two live contexts
+// get sets 0 and 1; (b) the pool is process-wide static state and its streams are never destroyed, so it must not be
+// relied on across hipDeviceReset(): acquire_streams probes a pooled set with hipStreamQuery and re-creates a dead one,
+// which covers a reset BETWEEN contexts, not one under a live context (that invalidates the context itself).
 struct StreamSet { hipStream_t main = nullptr; hipStream_t batch[svsdf::kMaxBatches] = {}; int slot = -1; };
 bool acquire_streams(int device, StreamSet &out);
 void release_streams(int device, StreamSet &s);

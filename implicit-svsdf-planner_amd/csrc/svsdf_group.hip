@@ -149,8 +149,6 @@ void merge_stats(svsdf_ctx *ctx) {
     t.piece_time_exact = std::max(t.piece_time_exact, a.piece_time_exact);
     t.bound_ratio = std::max(t.bound_ratio, a.bound_ratio);
     if (a.shader_clock_mhz > 0.0) t.shader_clock_mhz = (t.shader_clock_mhz > 0.0) ? std::min(t.shader_clock_mhz, a.shader_clock_mhz) : a.shader_clock_mhz;
-    t.small_ms = std::max(t.small_ms, a.small_ms);
-    t.small_path = std::max(t.small_path, a.small_path);
   }
   t.bound_mode_decided = 1;
   t.plan_settled = 1;

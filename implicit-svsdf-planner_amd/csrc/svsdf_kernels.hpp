@@ -462,7 +462,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     StatSlot &ss = ctl[i / kStatSlots].stat[i % kStatSlots];
     ss.solves = 0ull; ss.evals = 0ull; ss.scan = 0ull; ss.culled = 0ull; ss.round_scan = 0ull; ss.spec = 0ull;
 #ifdef SVSDF_SITE_STATS
-    for (int j = 0; j < 20; ++j) ss.pad[j] = 0ull;
+    for (int j = 0; j < 26; ++j) ss.pad[j] = 0ull;
 #endif
   }
   if (threadIdx.x == 0) {
@@ -801,7 +801,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
     }
     if (!culled) finish_scan();
     // Second exact cull (round 4; main points; needs a 1-Lipschitz shape SDF: true of every exact distance function, i.e.
-    // all 17 shapes, and self-checked per context by k_rbound -- a shape that fails runs without it).
+    // all 17 shapes; k_rbound samples the property per context as a sanity check -- a shape that fails it runs without the cull).
     // The first cull knows a chunk only by its bounding circle (|p - c| - rb: loose by up to the shape's circumradius --
     // 15 % of C3's points are inactive yet survive it).  After the scan the table VALUES are known.  For a time t of an
     // EVALUATED chunk's interval, within h of a table time t_k, the body-frame point q(t) = R(t)^T (p - x(t)) obeys
@@ -1460,14 +1460,14 @@ struct RoundOut {
   int n_emit;
   bool push_next, finished;
 };
-template <int SHAPE, int LP, int MODE>
+template <int SHAPE, int LP, int MODE, bool EAGER = false>
 __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *pose, const Chunk *chunks, int K, int nch,
                                             const double *__restrict__ px_, const double *__restrict__ py_,
                                             const GsipState &gs, size_t stride, int start, int a, double delta,
                                             double band_delta, double *__restrict__ res_sdf, double *__restrict__ res_t,
                                             double *__restrict__ res_gx, double *__restrict__ res_gy, unsigned &n_scan,
                                             RoundOut<(kMaxSlots + LP - 1) / LP> &out, unsigned short *clist, int clist_on,
-                                            unsigned long long (&rc)[8]) {
+                                            unsigned long long (&rc)[16]) {
   constexpr bool FULL = MODE == 1;
   unsigned long long tph = SVSDF_SITE_CLOCK();
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
@@ -1508,7 +1508,11 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
     for (int ps = 0; ps < NP; ++ps) {
       const int j = l + LP * ps;
       const size_t s_ = sample_slot(stride, ia, (j < kMaxSlots) ? j : 0);
-      const bool ld = PRE && j < kMaxSlots;
+      // EAGER (k_tail: the state sits in the wave's LDS or the callback is a latency chain): all 24 slots at once, before the
+      // state has arrived.  k_round (round 6): only the samples that exist and only when a round is to be closed -- one more
+      // dependent trip than the eager form, but the eager form read 4 x 24 sample entries for every point of every launch,
+      // also the points whose first round is still to be opened: k_round FETCH 170 -> 398 MB per C3 evaluation
+      const bool ld = PRE && (EAGER ? j < kMaxSlots : (phase_ != kPhaseNew && j < n_pre));
       g_pre[ps] = ld ? gs.sq_sdf[s_] : kUnsolved;
       t_pre[ps] = ld ? gs.sq_t[s_] : 0.0;
       th_pre[ps] = ld ? gs.sqth[s_] : 0.0;
@@ -1768,7 +1772,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             int bk = 0;
             if (found) {
               bool cu;
-              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1);
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8);
             }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
@@ -1834,7 +1838,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           int bk = 0;
           if (sidx < n_emit) {
             bool cu;
-            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1);
+            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8);
           }
           // hand the result to the lane that owns the sample: sub-group (j % SG) scanned sample j in pass j / SG
           const double rb = __shfl(bd, (l % SG) * 8, LP);
@@ -1910,7 +1914,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             int bk = 0;
             if (found) {
               bool cu;
-              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1);
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8);
             }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
@@ -2011,7 +2015,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   const int n_act = ctl->n_active[it];
   const int ppb = blockDim.x / LP;  // points per block (== PPB)
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
-  unsigned long long rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  unsigned long long rc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only (8 .. 15: the seed scans' evaluation site)
   const unsigned long long t_wave0 = SVSDF_SITE_CLOCK();
   unsigned long long tfl = t_wave0;
   const int K = trg->K;
@@ -2124,6 +2128,12 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     StatSlot *ss = stat_slot(ctl->stat);
     for (int i = 0; i < 8; ++i) if (rc[i]) atomicAdd(&ss->pad[12 + i], rc[i]);
   }
+  {   // the seed scans' evaluation site: wave-level executions (pad[20]) and evaluating lanes (pad[21])
+    unsigned long long ex = rc[8], ln = rc[12];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { ex += __shfl_xor(ex, m, 64); ln += __shfl_xor(ln, m, 64); }
+    if ((threadIdx.x & 63) == 0 && ex) { StatSlot *ss = stat_slot(ctl->stat); atomicAdd(&ss->pad[20], ex); atomicAdd(&ss->pad[21], ln); }
+  }
 #endif
   if constexpr (MODE != 0) {
     unsigned long long tc = n_scan;
@@ -2224,7 +2234,11 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   }
   const TrajL tr = stage_traj(trg, tab_lds + 4 * (size_t)K + 4 * (size_t)nch);  // ends with __syncthreads (the only block barrier)
   const size_t tables = poly_lds_doubles<SHAPE>(sp.nverts) + 4 * (size_t)K + 4 * (size_t)nch + (size_t)traj_lds_doubles(tr.N);
-  char *wave_lds = reinterpret_cast<char *>(tail_lds + ((tables + 1) & ~(size_t)1)) + (threadIdx.x >> 6) * kTailWaveLds;
+  const bool local = it0 == 0 && (clist_on & 4) != 0;   // (bit 2 of clist_on: the host's switch, SVSDF_TAIL_LOCAL=0 turns it off; see below)
+  // per-wave stride: the wave-local GSIP block (the last part of a wave's region) only exists when it is used (launch_tail
+  // sizes the launch's LDS the same way)
+  const size_t wave_stride = local ? kTailWaveLds : kTailWaveLds - kTailLocalBytes;
+  char *wave_lds = reinterpret_cast<char *>(tail_lds + ((tables + 1) & ~(size_t)1)) + (threadIdx.x >> 6) * wave_stride;
   unsigned short *clist_w = reinterpret_cast<unsigned short *>(wave_lds + ((ladder_lds_bytes(2) + 15) & ~(size_t)15));
   unsigned *qlist = reinterpret_cast<unsigned *>(clist_w + 2 * kMaxCand);
   // Round 5: when the WHOLE GSIP loop runs here (it0 == 0: every point arrives fresh from k_classify, no round open), the
@@ -2232,9 +2246,8 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   // global memory: round_point and the solve passes are handed a GsipState whose pointers address that LDS block (generic
   // pointers; slot = sample * 2 + half), nothing else changes.  A GSIP step was four dependent trips to L2 (state,
   // samples, the solve's inputs, its results) of ~ 1.5 us each around ~ 20 us of arithmetic, ten steps per point.
-  const bool local = it0 == 0 && (clist_on & 4) != 0;   // (bit 2 of clist_on: the host's switch, SVSDF_TAIL_LOCAL=0 turns it off)
   GsipState gl = gs;
-  {
+  if (local) {
     double *ld = reinterpret_cast<double *>(qlist + 64);
     gl.r = ld; gl.theta0 = ld + 2; gl.theta_res = ld + 4;
     gl.sqx = ld + 6; gl.sqy = gl.sqx + 2 * kMaxSlots; gl.sqth = gl.sqy + 2 * kMaxSlots; gl.sq_ub = gl.sqth + 2 * kMaxSlots;
@@ -2251,7 +2264,7 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   const int h = lane >> 5, l = lane & (LP - 1);
   const unsigned lt_mask = (1u << l) - 1u;
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_spec = 0, n_rscan = 0;
-  unsigned long long rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only
+  unsigned long long rc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only (8 .. 15: the seed scans' evaluation site)
   unsigned long long sc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_wave0 = SVSDF_SITE_CLOCK();
   int n_emit_tot = 0;
@@ -2301,7 +2314,7 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     ro.list_me[0] = false; ro.mlist[0] = 0u; ro.n_emit = 0; ro.push_next = false; ro.finished = false;
     if (a >= 0) {
       const double dl = (steps >= all_after) ? 1e300 : delta, bd = (steps >= all_after) ? 1e300 : band_delta;
-      round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, ga, stride_a, start, local ? h : a, dl, bd, res_sdf, res_t, res_gx,
+      round_point<SHAPE, LP, MODE, true>(sp, pose, chunks, K, nch, px_, py_, ga, stride_a, start, local ? h : a, dl, bd, res_sdf, res_t, res_gx,
                                    res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc);
       ++steps;
       if (ro.n_emit > 0) own = true;
@@ -2360,6 +2373,12 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     StatSlot *ss = stat_slot(ctl->stat);
     for (int i = 0; i < 8; ++i) if (rc[i]) atomicAdd(&ss->pad[12 + i], rc[i]);
     for (int i = 8; i < 11; ++i) if (sc[i]) atomicAdd(&ss->pad[i], sc[i]);
+  }
+  {
+    unsigned long long ex = rc[8], ln = rc[12];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { ex += __shfl_xor(ex, m, 64); ln += __shfl_xor(ln, m, 64); }
+    if (lane == 0 && ex) { StatSlot *ss = stat_slot(ctl->stat); atomicAdd(&ss->pad[20], ex); atomicAdd(&ss->pad[21], ln); }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {   // site executions (0 .. 3) and evaluating lanes (4 .. 7), like k_solve

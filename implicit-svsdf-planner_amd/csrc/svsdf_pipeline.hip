@@ -46,7 +46,25 @@ bool acquire_streams(int device, StreamSet &out) {
   if ((size_t)device >= g_pool.size()) g_pool.resize((size_t)device + 1);
   std::vector<PoolEntry> &pool = g_pool[(size_t)device];
   for (size_t k = 0; k < pool.size(); ++k)
-    if (!pool[k].in_use) { pool[k].in_use = true; out = pool[k].set; return true; }   // lowest free slot first
+    if (!pool[k].in_use) {   // lowest free slot first
+      // A pooled set outlives its contexts on purpose (never destroyed: see svsdf_ctx.hpp) -- but not a hipDeviceReset(),
+      // after which its handles dangle.  An idle stream answers hipStreamQuery with success; anything but
+      // success / not-ready means the handle is dead: the slot gets a fresh set, in the same fixed order.
+      bool alive = true;
+      {
+        const hipError_t q = hipStreamQuery(pool[k].set.main);
+        if (q != hipSuccess && q != hipErrorNotReady) { alive = false; (void)hipGetLastError(); }
+      }
+      if (!alive) {
+        StreamSet fresh;
+        fresh.slot = (int)k;
+        bool ok = hipStreamCreateWithFlags(&fresh.main, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; b < kMaxBatches && ok; ++b) ok = hipStreamCreateWithFlags(&fresh.batch[b], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) return false;
+        pool[k].set = fresh;
+      }
+      pool[k].in_use = true; out = pool[k].set; return true;
+    }
   PoolEntry e;
   e.set.slot = (int)pool.size();
   bool ok = hipStreamCreateWithFlags(&e.set.main, hipStreamNonBlocking) == hipSuccess;
@@ -226,6 +244,12 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   }
 }
 
+// LDS one k_tail block asks for (Polygon edges in LDS or not), and whether the device grants it
+size_t tail_lds_bytes(const svsdf_ctx *ctx, bool poly_lds, bool local) {
+  const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? (size_t)svsdf::kPolyEdgeDoubles * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
+  return lds_tables + (kTailBlock / 64) * (local ? kTailWaveLds : kTailWaveLds - kTailLocalBytes);
+}
+
 // k_tail: every GSIP iteration of batch b from `it0` on, in one launch (two points per wave, solved in the wave).
 void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const int mode = bound_mode_of(ctx);
@@ -239,12 +263,16 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   if (ctx->have_prev_nactive && it0 <= ctx->prev_tail_iter && it0 < kMaxIter)
     pts = std::min<long long>(pts, ctx->prev_nactive[it0] / std::max(1, ctx->nbatch) * 5 / 4 + 64);
   bool poly_lds = ctx->poly_lds;
+  // the wave-local copy of the GSIP state only where it is used: the whole loop in the tail (it0 == 0) with the switch on;
+  // when it does not fit, the state stays in global memory (same bits)
+  bool local = ctx->tail_local && it0 == 0;
   size_t lds = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const size_t lds_tables = ((table_lds_doubles(ctx) + (size_t)traj_lds_doubles(ctx->N) + (poly_lds ? (size_t)svsdf::kPolyEdgeDoubles * (size_t)ctx->sp.nverts : 0)) * sizeof(double) + 15) & ~(size_t)15;
-    lds = lds_tables + (kTailBlock / 64) * kTailWaveLds;
-    if (lds <= ctx->lds_limit || !poly_lds) break;
-    poly_lds = false;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    lds = tail_lds_bytes(ctx, poly_lds, local);
+    if (lds <= ctx->lds_limit) break;
+    if (local) local = false;
+    else if (poly_lds) poly_lds = false;
+    else break;
   }
   if (lds > ctx->lds_limit) {
     if (ctx->launch_err.empty()) ctx->launch_err = "trajectory too long for the LDS pose table (k_tail)";
@@ -257,7 +285,7 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const TailLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it0, mode,
                      sel, ctx->select_delta, all_after, ppw, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                     ctx->d_ctl + b, ctx->round_list | (ctx->tail_local ? 4 : 0), ctx->prune};
+                     ctx->d_ctl + b, ctx->round_list | (local ? 4 : 0), ctx->prune};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_tail(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a) && ctx->launch_err.empty())
@@ -281,6 +309,9 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
 // off.  Any choice gives the same bits.
 int choose_tail_iter(const svsdf_ctx *ctx) {
   if (ctx->tail_mode == -2) return -1;
+  //  a trajectory whose tables leave no room for the tail's per-wave state runs the launch chain, which needs
+  // less LDS per block, instead of failing the evaluation (128 pieces on a device with 64 KB per block)
+  if (tail_lds_bytes(ctx, false, false) > ctx->lds_limit) return -1;
   if (ctx->tail_mode >= 0) return std::min(ctx->tail_mode, (int)kMaxIter - 2);
   if (!ctx->have_prev_nactive) return -1;   // first evaluation of a point set: the interior count is not known yet
   const long long below = ctx->tail_below > 0 ? ctx->tail_below : (long long)ctx->n_cu * 24;
@@ -561,6 +592,9 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
       ctx->block_partials_cap = (size_t)grid * plen;
     }
     const size_t lds = ((size_t)traj_lds_doubles(N) + (kBlock / 64) * plen) * sizeof(double);  // one accumulator row per wave
+    if (lds > ctx->lds_limit)   // (98 KB at 128 pieces: fits gfx950's 160 KB; a clear error instead of a raw launch failure elsewhere)
+      return fail(ctx, SVSDF_ERR_INVALID, "trajectory too long for the reduction's LDS accumulator rows (" + std::to_string(lds) + " B of " +
+                  std::to_string(ctx->lds_limit) + " B per block)");
     // small clouds (<= 1024 points): assembly, block reduction, fixed-order final sum, suffix sum and counters in ONE
     // launch whose last block writes the result to the device buffer and straight into the pinned host buffer (k_reduce);
     // larger ones: the assembly, then k_final (one wave per entry) and k_finish as launches of their own

@@ -70,8 +70,7 @@ class Stats(C.Structure):
                 ("round_ms", C.c_double), ("round_ms_sum", C.c_double), ("batches", C.c_int),
                 ("speculative_evals", C.c_ulonglong), ("plan_settled", C.c_int), ("tail_iter", C.c_int),
                 ("tail_launches", C.c_uint), ("tail_points", C.c_ulonglong), ("tail_ms", C.c_double),
-                ("tail_ms_sum", C.c_double), ("shader_clock_mhz", C.c_double), ("fanout_ms", C.c_double),
-                ("small_ms", C.c_double), ("small_path", C.c_int)]
+                ("tail_ms_sum", C.c_double), ("shader_clock_mhz", C.c_double), ("fanout_ms", C.c_double)]
 
 
 class Plan(C.Structure):

@@ -407,9 +407,6 @@ typedef struct svsdf_stats {
   double fanout_ms;                   /* multi-device contexts: host wall time of the evaluation that is neither a device's
                                          pipeline nor the combine -- waking the per-device threads (post -> the last thread
                                          starts) + joining them (the last thread done -> the caller runs again) */
-  double small_ms;                    /* HIP-event time of the fused small-cloud kernel (k_small), when it ran (profiling on) */
-  int small_path;                     /* 1: the last evaluation ran as ONE launch (k_small: tables, main solve, GSIP loop and
-                                         reduction fused; clouds of a few thousand points), 0: the launch chain */
 } svsdf_stats;
 int svsdf_last_stats(const svsdf_ctx *ctx, svsdf_stats *out);
 

@@ -14,6 +14,7 @@
 #   ab:<variants>[:<configs>[:<points>]]   tools/exp_variants.py (variant builds vs the default library, identity hash)
 #   pytest[:<expr>]   pytest -m gpu [-k expr]
 #   fuzz:<cases>:<seed>   tools/fuzz_parity.py campaign
+#   ktp:<config>:<points>[:<batches>]   the same at a given cloud size through tools/prof_eval.py (one stripe of a multi-GPU run)
 #   kt:<config>  rocprofv3 --kernel-trace --stats of the bench command on one config, one batch (SVSDF_BATCHES=1) + timeline
 #   pmc:<config> separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*) of the same command -> tools/pmc_summary.py
 #   pmcref[:<map>]  PMC passes (instruction mix, wave cycles, instruction cache) of reference-scale callbacks
@@ -51,6 +52,12 @@ for STEP in "$@"; do
        KS=$(find /tmp/kt_$TAG -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/kt_$TAG -name '*kernel_trace.csv' | head -1)
        [ -n "$KS" ] && cp $KS $OUT/${TAG}_bench_${ARG}_b1_kernel_stats.csv
        [ -n "$KT" ] && python $ROOT/tools/timeline.py $KT 6 > $OUT/${TAG}_bench_${ARG}_b1_timeline.txt 2>&1) ;;
+    ktp)   # ktp:<config>:<points>[:<batches>]  kernel trace + per-launch timeline of one evaluation at a given cloud size (a multi-GPU stripe: C4:500000)
+      IFS=: read -r C P B <<< "$ARG"
+      (cd /tmp && rm -rf /tmp/ktp_$TAG && SVSDF_BATCHES=${B:-} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktp_$TAG -o kt -- python -u $ROOT/tools/prof_eval.py $C $P 8 > $OUT/${TAG}_ktp_${C}_${P}_b${B:-auto}.log 2>&1
+       KS=$(find /tmp/ktp_$TAG -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/ktp_$TAG -name '*kernel_trace.csv' | head -1)
+       [ -n "$KS" ] && cp $KS $OUT/${TAG}_${C}_${P}_b${B:-auto}_kernel_stats.csv
+       [ -n "$KT" ] && python $ROOT/tools/timeline.py $KT 7 > $OUT/${TAG}_${C}_${P}_b${B:-auto}_timeline.txt 2>&1) ;;
     pmc)
       (cd /tmp && for CTR in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
          D=/tmp/pmc_${TAG}_$(echo $CTR | tr ' ' '_'); rm -rf $D

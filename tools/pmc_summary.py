@@ -27,3 +27,10 @@ for k, v in s.items():
     if 'rocclr' in k or not v.get('SQ_WAVES'): continue
     print(f"{k:20s} {v['SQ_WAVES']/steps:10.0f} {v['SQ_INSTS_VALU']/v['SQ_WAVES']:10.0f} {v['SQ_INSTS_SALU']/v['SQ_WAVES']:10.0f} {v['SQ_INSTS_LDS']/v['SQ_WAVES']:9.0f} {v['SQ_BUSY_CYCLES']/steps:20.4g} {v['GRBM_GUI_ACTIVE']/steps:20.4g}")
 print(f"TRAFFIC_BYTES {int((2*tf+tw)*1e6)}")
+# every kernel of the evaluation itself (k_*: the pipeline's own launches; not the one-time point upload -- k_points_* and the
+# rocprim sort -- nor k_rbound at svsdf_create)
+path = lambda k: k.startswith('k_') and not k.startswith('k_points') and not k.startswith('k_rbound')
+af = sum(v['FETCH_SIZE'] for k, v in f.items() if path(k)) / steps / 1024
+aw = sum(v['WRITE_SIZE'] for k, v in w.items() if path(k)) / steps / 1024
+print(f"whole evaluation (every k_* launch of the path): HBM traffic = 2*FETCH + WRITE = {2*af+aw:.1f} MB per evaluation")
+print(f"TRAFFIC_TOTAL_BYTES {int((2*af+aw)*1e6)}")

@@ -34,7 +34,7 @@ for cfg in cfgs:
         if c.stats().get("plan_settled", 1):
             break
     c.eval_penalty(w["coeffs"], w["T"])
-    out = (C.c_ulonglong * 20)()
+    out = (C.c_ulonglong * 26)()
     c.L.svsdf_debug_site_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     rc = c.L.svsdf_debug_site_stats(c.ctx, out)
     assert rc == 0, rc
@@ -50,5 +50,6 @@ for cfg in cfgs:
     names = ["close", "candidate list", "samples + cheap bound", "seed scans", "selection", "flush", "whole wave", "staging"]
     tot = max(out[18], 1)
     print("  k_round wave cycles: " + ", ".join("%s %.3e (%.2f)" % (n, out[12 + i], out[12 + i] / tot) for i, n in enumerate(names)))
+    print("  k_round seed-scan evaluation site: executions %d, evaluating lanes %d, occupancy %.3f" % (out[20], out[21], out[21] / max(64 * out[20], 1)))
     st = c.stats()
     print("  ", {k: st[k] for k in ("solves", "sdf_evals", "scan_evals", "round_scan_evals", "gsip_bound_mode", "batches")})
