@@ -120,6 +120,7 @@ struct svsdf_ctx {
   bool block_env = false;      // env SVSDF_BLOCK pins the solve kernel's block size (default: by LDS footprint)
   int late_iter = 4, first_iters = 12, it_done = 0, round_lp8_iters = 3, delta_all_iter = 5;
   int n_cu = 256;
+  int round_blocks_per_cu = 4;   // k_round: blocks per CU the grid is capped at (its blocks fetch further iterations themselves); env SVSDF_ROUND_BPC
   double wall_clock_khz = 100000.0;   // hipDeviceAttributeWallClockRate: rate of the constant counter of the clock probe
   bool adaptive_iters = true;
   bool ub_full = false;        // k_round scans every new GSIP sample (seed = tightest layer-1 bound, reused by k_solve)

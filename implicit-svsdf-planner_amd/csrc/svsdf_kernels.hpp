@@ -87,6 +87,7 @@ struct BatchCtl {
   int n_solve[kMaxIter + 2];      // [i] = sample solves requested for iteration i
   int n_seed[kMaxIter + 2];       // [i] = circle samples emitted in iteration i (statistics)
   unsigned work[kWorkCounters];   // dynamic work-fetch cursors, one per solve launch
+  unsigned rwork[kMaxIter + 2];   // the same for the k_round launches (block iterations beyond the grid's first generation)
   int nonfinite;
   int n_int;                      // ctl[0] only: interior points of the whole shard so far = next compact interior index
   // work counters (statistics), added to by every wave at the end of a launch: one address takes ~80 M atomics / s
@@ -454,6 +455,7 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     BatchCtl &c = ctl[b];
     for (int r = 0; r < kMaxIter + 2; ++r) { c.n_active[r] = 0; c.n_solve[r] = 0; c.n_seed[r] = 0; }
     for (int r = 0; r < kWorkCounters; ++r) c.work[r] = 0u;
+    for (int r = 0; r < kMaxIter + 2; ++r) c.rwork[r] = 0u;
     c.nonfinite = 0;
     c.n_int = 0;
     c.clk[0] = 0ull; c.clk[1] = 0ull;
@@ -639,6 +641,24 @@ struct Grp {
     if constexpr (G >= 16) min_dk_step<3>(d, k);
     if constexpr (G >= 32) min_dk_step<4>(d, k);
   }
+  // min of a double over the group; all lanes get the result
+  __device__ static __forceinline__ double min_d(double v) {
+    if constexpr (G >= 2) v = dmin(v, xchg<0>(v));
+    if constexpr (G >= 4) v = dmin(v, xchg<1>(v));
+    if constexpr (G >= 8) v = dmin(v, xchg<2>(v));
+    if constexpr (G >= 16) v = dmin(v, xchg<3>(v));
+    if constexpr (G >= 32) v = dmin(v, xchg<4>(v));
+    return v;
+  }
+  // lexicographic min of (d, k) over the group like min_dk, in two plain butterflies (round 6): the minimum VALUE first
+  // (3 instructions per step), then the smallest index among the lanes that hold it (2 per step) -- 5 instead of the 11 a
+  // step of the pair butterfly costs (three exchanges, three compares, two mask operations, three selects).  Same pair: the
+  // lexicographic minimum IS the smallest index among the carriers of the smallest value.  (A NaN never carries it.)
+  __device__ static __forceinline__ void min_dk2(double &d, int &k) {
+    const double m = min_d(d);
+    k = min_i((d == m) ? k : 0x7fffffff);
+    d = m;
+  }
   // bit i set <=> lane i of this group has pred
   __device__ static __forceinline__ unsigned ballot(bool pred) {
     if constexpr (G == 1) return pred ? 1u : 0u;
@@ -717,9 +737,15 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
     }
   };
   auto finish_scan = [&]() {
-    Grp<G>::min_dk(d_lane, k_lane);
-    // (lexicographic minimum with the initial (1e9, none), like the sequential update it replaces)
-    if (d_lane < 1e9 || (d_lane == 1e9 && k_lane != 0x7fffffff)) { best_d = d_lane; best_k = k_lane; }
+    if (best_d < 1e9) {
+      // (group-uniform) best_d = the smallest of all evaluated values = min over the lanes of d_lane: the earliest index is
+      // the smallest k_lane among the lanes that hold that value -- one integer butterfly instead of the pair butterfly
+      best_k = Grp<G>::min_i((d_lane == best_d) ? k_lane : 0x7fffffff);
+    } else {
+      Grp<G>::min_dk(d_lane, k_lane);
+      // (lexicographic minimum with the initial (1e9, none), like the sequential update it replaces)
+      if (d_lane < 1e9 || (d_lane == 1e9 && k_lane != 0x7fffffff)) { best_d = d_lane; best_k = k_lane; }
+    }
   };
   if constexpr (LITE) {
     const int nl = (ncl < 0) ? nch : ncl;
@@ -733,7 +759,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
       const double d2 = ex * ex + ey * ey;
       if (d2 < d2_loc) { d2_loc = d2; c_loc = c; }
     }
-    Grp<G>::min_dk(d2_loc, c_loc);
+    Grp<G>::min_dk2(d2_loc, c_loc);
     const int c0 = c_loc;
     eval_chunk(c0);
     int j = 0;
@@ -770,7 +796,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
       if (lb < lb_loc) { lb_loc = lb; c_loc = c; }
       lbc_loc = dmin(lbc_loc, lb - ch.slack);
     }
-    Grp<G>::min_dk(lb_loc, c_loc);
+    Grp<G>::min_dk2(lb_loc, c_loc);
     if constexpr (G >= 2) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<0>(lbc_loc));
     if constexpr (G >= 4) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<1>(lbc_loc));
     if constexpr (G >= 8) lbc_loc = dmin(lbc_loc, Grp<G>::template xchg<2>(lbc_loc));
@@ -1632,7 +1658,11 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       // + r follows).  The scans and the cheap bound below walk this list (ascending, in LDS) instead of all chunks:
       // same seeds, same bounds; most of a long path's chunks drop out once the circle is small (rounds >= 3).
       int ncl = -1;
-      {
+      // (round 6) a circle of radius >= 8 m -- the first round's r0 = 10 (SWM:927), i.e. EVERY point of the chain's first
+      // launch -- reaches most of a path: the list then holds (nearly) all chunks or overflows (ncl = -1) and the scans walk
+      // everything anyway, but building it cost two passes over all chunks with a correctly rounded root each, a third of that
+      // launch's non-scan instructions.  Any list is exact (ncl = -1: all chunks), so this only moves time.
+      if (fabs(r) < 8.0) {
         double u = 1e300;
         for (int c = l; c < nch; c += LP) {
           const Chunk ch = chunks[c];
@@ -1685,6 +1715,9 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         sqx_l[ps] = 0.0; sqy_l[ps] = 0.0; th_l[ps] = 0.0;
         if (valid[ps]) {
           const size_t s = sample_slot(stride, ia, j);
+          // (sincos_exact -- one argument reduction for the pair -- was measured here in round 6: same bits, fewer instructions,
+          // but 18 more live registers in the three unrolled sample passes of the 8-lane kernels: 128 -> 146 VGPRs, a wave per
+          // SIMD less; the two library calls stay)
           const double qx = cx + 1.0 * r * cos(theta);
           const double qy = cy + 1.0 * r * sin(theta);
           sqx_l[ps] = qx; sqy_l[ps] = qy;
@@ -1988,8 +2021,14 @@ constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
 // MODE: 0 cheap bound (nearest chunk), 1 full (every new sample scanned), 2 lazy (cheap bound for all, the sample's own
 // table scan only for those within `band_delta` of the best cheap bound -- the ones the cheap mode would solve), 3 anchor
 // (every third sample scanned, the others only if their Lipschitz bound from the anchors reaches the selection band)
+#ifndef SVSDF_ROUND_WAVES
+#define SVSDF_ROUND_WAVES 1   // waves per SIMD the register allocation of k_round aims at (1: whatever its registers allow = 4).  Round 6
+                              // measured 5 (96 VGPRs, 68 - 190 B of scratch per lane): + 1 ... 4 % -- and k_round<star, 8, anchor> then faulted
+                              // (memory aperture violation in the second evaluation of a 8 k-point cloud, tests/test_gpu_plan.py; gone with 4
+                              // waves, i.e. without scratch, and not understood): no spilling variant of this kernel is shipped
+#endif
 template <int SHAPE, int LP, int MODE>
-__global__ void __launch_bounds__(kRoundBlock)
+__global__ void __launch_bounds__(kRoundBlock, SVSDF_ROUND_WAVES)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
         const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta, double band_delta,
@@ -2012,6 +2051,7 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   __shared__ int s_wsum[3][kWaves];
   __shared__ int s_base[2];
   __shared__ unsigned short s_clist[PPB * kMaxCand];   // per point slot: candidate chunks of its round
+  __shared__ int s_next[2];                        // the block's next iteration (dynamic fetch), double-buffered by iteration parity
   const int n_act = ctl->n_active[it];
   const int ppb = blockDim.x / LP;  // points per block (== PPB)
   if (n_act <= 0 || (int)blockIdx.x * ppb >= n_act) return;
@@ -2042,8 +2082,15 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
   unsigned n_scan = 0;   // table evaluations of the cooperative seed scans (FULL)
   const unsigned lt_mask = (1u << l) - 1u;
   int nbuf = 0;          // block iterations buffered since the last flush (block-uniform)
+  // Block iterations (ppb points each): the first is the block's own (block index: no atomic), the following ones come from
+  // the launch's cursor (round 6).  The grid-stride loop this replaces gave every block the same NUMBER of iterations, but an
+  // iteration costs anything between a few state loads (its points only close a round and finish) and 18 - 21 seed scans per
+  // point (they open one), and Morton-sorted neighbours behave alike: counters showed the launches of the first GSIP
+  // iterations at 60 - 70 % of their wave slots on average -- blocks that drew light iterations had left, the launch waited
+  // for those that drew heavy ones (SQ_WAVE_CYCLES / duration: 2 450 of 4 096 waves resident in iteration 2 of C3).
   // block-uniform trip count; lane groups without a point still take part in the flushes
-  for (int e0 = (int)blockIdx.x * ppb; e0 < n_act; e0 += (int)gridDim.x * ppb) {
+  int par = 0;
+  for (int e0 = (int)blockIdx.x * ppb; e0 < n_act;) {
     const int e = e0 + hw;
     const bool active = e < n_act;
     int a = 0;
@@ -2064,7 +2111,11 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
       s_emit[ent] = (unsigned short)ro.n_emit;
     }
     ++nbuf;
-    const bool last = e0 + (int)gridDim.x * ppb >= n_act;
+    if (threadIdx.x == 0) s_next[par] = ((int)gridDim.x + (int)atomicAdd(&ctl->rwork[it], 1u)) * ppb;
+    __syncthreads();
+    e0 = s_next[par];   // (the other parity is written one iteration later: no wave can still be reading it)
+    par ^= 1;
+    const bool last = e0 >= n_act;
     if (nbuf < LP && !last) continue;
     // ---- flush: one block scan, one set of list atomics, then every point slot writes the entries of its points
     tfl = SVSDF_SITE_CLOCK();

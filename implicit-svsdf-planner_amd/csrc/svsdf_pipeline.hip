@@ -87,6 +87,16 @@ void release_streams(int device, StreamSet &s) {
   s = StreamSet{};
 }
 
+// SVSDF_DEBUG_SYNC=1 (diagnosis only): every launch of the chain is followed by a stream synchronisation and named on stderr
+// BEFORE it runs, so that a device fault (which aborts the process at the next synchronisation) is pinned to one launch.
+static bool debug_sync_on() { static const bool on = [] { const char *e = std::getenv("SVSDF_DEBUG_SYNC"); return e && std::atoi(e) != 0; }(); return on; }
+static void debug_sync(hipStream_t st, const char *what, int a, int b) {
+  if (!debug_sync_on()) return;
+  std::fprintf(stderr, "[svsdf] launched %s (%d, %d) ... ", what, a, b);
+  const hipError_t e = hipStreamSynchronize(st);
+  std::fprintf(stderr, "%s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+}
+
 size_t next_event(svsdf_ctx *ctx) {
   if (ctx->ev_used == ctx->ev_pool.size()) {
     hipEvent_t e = nullptr;
@@ -195,6 +205,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
                       cull2 ? d_rot : nullptr, ctx->slack_max};
   if (!launch_k_solve(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds_total, st, a) && ctx->launch_err.empty())
     ctx->launch_err = "k_solve: shape not compiled into this build";
+  debug_sync(st, "k_solve", G, work_idx);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -230,13 +241,14 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   // active: throughput, not latency) also runs faster with 8 lanes and three sample passes per point -- measured round 3,
   // SVSDF_ROUND_LP8_ITERS 2 / 3 / 4 / 6 / all: C3 6.15 / 5.97 / 6.12 / 6.33 / 6.45 ms, NS 7.49 / 7.24 / 7.21 / 7.31 / 7.58
   const int lp = (it < ctx->round_lp8_iters) ? 8 : 32;
-  const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, (long long)(256 * 16 * 64) / kRoundBlock);
+  const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, (long long)ctx->n_cu * ctx->round_blocks_per_cu);
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it, delta,
                       band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b, ctx->round_list};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_round(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, lp, mode, grid, lds, st, a) && ctx->launch_err.empty())
     ctx->launch_err = "k_round: shape not compiled into this build";
+  debug_sync(st, "k_round", lp * 10 + mode, it);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -290,6 +302,7 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_tail(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a) && ctx->launch_err.empty())
     ctx->launch_err = "k_tail: shape not compiled into this build";
+  debug_sync(st, "k_tail", mode, it0);
   if (ctx->profile) {
     e1 = next_event(ctx);
     (void)hipEventRecord(ctx->ev_pool[e1], st);
@@ -324,6 +337,7 @@ void launch_classify(svsdf_ctx *ctx, hipStream_t st, int b) {
   const ClassifyLaunch a{ctx->d_traj, ctx->sp, ctx->d_px, ctx->d_py, ctx->d_sdf, ctx->d_t, ctx->d_res_sdf, ctx->d_res_t,
                          ctx->d_res_gx, ctx->d_res_gy, ctx->gs, ctx->d_ctl + b, &ctx->d_ctl->n_int, (int)ctx->icap};
   (void)launch_k_classify(ctx->cfg.shape_id, grid, lds, st, a);
+  debug_sync(st, "k_classify", b, 0);
 }
 
 // Upload (coeffs, T), update traj_duration like SweptVolumeManager::updateTraj (SWM:376-385),
@@ -1011,6 +1025,10 @@ int set_batches(svsdf_ctx *ctx, int nb) {
   ctx->nbatch = nb;
   std::vector<BatchCtl> hc(kMaxBatches);
   std::memset(hc.data(), 0, sizeof(BatchCtl) * kMaxBatches);
+  // (Round 6 measured batches that are STRIPES of the Morton order -- points b, b + nb, ... -- instead of contiguous parts:
+  // their launch chains then weigh the same and end together, where the contiguous thirds of C3 end 300 us apart.  It is 3 - 5 %
+  // SLOWER (C3 5.60 -> 5.77 ms, a 500 k-point C4 stripe 3.61 -> 3.79): identical chains run in lockstep, all in k_round or all
+  // in k_solve at the same time, and the overlap of unlike phases is what the concurrent batches are for.)
   for (int b = 0; b < nb; ++b) {
     const size_t s = Ps * (size_t)b / nb, e = Ps * (size_t)(b + 1) / nb;
     ctx->bstart[b] = (int)s;

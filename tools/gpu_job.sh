@@ -17,6 +17,7 @@
 #   ktp:<config>:<points>[:<batches>]   the same at a given cloud size through tools/prof_eval.py (one stripe of a multi-GPU run)
 #   kt:<config>  rocprofv3 --kernel-trace --stats of the bench command on one config, one batch (SVSDF_BATCHES=1) + timeline
 #   pmc:<config> separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*) of the same command -> tools/pmc_summary.py
+#   pmcl:<config>:<points>[:<batches>]   per-launch instruction counters of one evaluation (default: one batch)
 #   pmcref[:<map>]  PMC passes (instruction mix, wave cycles, instruction cache) of reference-scale callbacks
 #   profround:<config>   tools/profile_round.sh: bench line + kernel stats + separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ_*) + one-batch trace
 #   smoke        __graft_entry__.smoke()
@@ -57,13 +58,20 @@ for STEP in "$@"; do
       (cd /tmp && rm -rf /tmp/ktp_$TAG && SVSDF_BATCHES=${B:-} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktp_$TAG -o kt -- python -u $ROOT/tools/prof_eval.py $C $P 8 > $OUT/${TAG}_ktp_${C}_${P}_b${B:-auto}.log 2>&1
        KS=$(find /tmp/ktp_$TAG -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/ktp_$TAG -name '*kernel_trace.csv' | head -1)
        [ -n "$KS" ] && cp $KS $OUT/${TAG}_${C}_${P}_b${B:-auto}_kernel_stats.csv
-       [ -n "$KT" ] && python $ROOT/tools/timeline.py $KT 7 > $OUT/${TAG}_${C}_${P}_b${B:-auto}_timeline.txt 2>&1) ;;
+       [ -n "$KT" ] && python $ROOT/tools/timeline.py $KT 5 > $OUT/${TAG}_${C}_${P}_b${B:-auto}_timeline.txt 2>&1) ;;
     pmc)
       (cd /tmp && for CTR in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
          D=/tmp/pmc_${TAG}_$(echo $CTR | tr ' ' '_'); rm -rf $D
          timeout 400 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $D -o p -- python -u $ROOT/tools/prof_eval.py $ARG $(python -c "import sys; sys.path[:0]=['$ROOT/tools']; from svsdf_cfg import default_points; print(default_points('$ARG'))") 6 > /tmp/pmc.log 2>&1
        done
        python $ROOT/tools/pmc_agg.py $(find /tmp/pmc_${TAG}_* -name '*counter_collection.csv') > $OUT/${TAG}_pmc_$ARG.txt 2>&1) ;;
+    pmcl)   # pmcl:<config>:<points>[:<batches>]  per-LAUNCH instruction counters of one evaluation (tools/pmc_per_launch.py)
+      IFS=: read -r C P B <<< "$ARG"
+      (cd /tmp && for CTR in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" ${PMCL_EXTRA:+"SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" "SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F64 SQ_INST_CYCLES_SALU SQ_IFETCH" "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LEVEL_WAVES SQ_CYCLES"}; do
+         D=/tmp/pmcl_${TAG}_$(echo $CTR | tr ' ' '_'); rm -rf $D
+         SVSDF_BATCHES=${B:-1} timeout 300 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $D -o p -- python -u $ROOT/tools/prof_eval.py $C $P 6 > /tmp/pmcl.log 2>&1 || tail -3 /tmp/pmcl.log
+         python $ROOT/tools/pmc_per_launch.py $(find $D -name '*counter_collection.csv' | head -1) 4 > $OUT/${TAG}_pmcl_${C}_${P}_b${B:-1}_$(echo $CTR | cut -d' ' -f1).txt 2>&1
+       done) ;;
     pmcref)
       (cd /tmp && rocprofv3 -L > $OUT/${TAG}_counters_available.txt 2>&1
        for CTR in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INSTS_FLAT"; do
