@@ -585,14 +585,14 @@ def sustained(r, steps=300, seed=11):
                     "torch's ~ 1e6 objects put one 35 ms pause at a random step (profiles/r05_stall_probe.txt)"}
 
 
-def stripe_report(r, devices, steps=3):
+def stripe_report(r, devices, steps=5):
     """8-GPU readiness that can be measured on any box: every stripe's own device time (the stripes
     evaluated ONE AFTER THE OTHER with per-launch HIP events, so that stripes sharing a GPU do not stretch each other),
     the plan each stripe follows, and -- concurrently again -- what the fan-out costs the host per evaluation."""
     c = r.ctx
     G = len(devices)
     c.set_group_serial(True)
-    c.set_profiling(True)
+    c.set_profiling(3)     # span only: the per-launch events of level 1 stretch a 500 k-point stripe by ~ 5 % (3.85 vs 3.67 ms)
     r.step()
     dev = np.zeros((steps, G))
     for k in range(steps):
@@ -600,6 +600,10 @@ def stripe_report(r, devices, steps=3):
         for j in range(G):
             dev[k, j] = c.group_stripe(j)["stats"]["device_ms"]
     info = [c.group_stripe(j) for j in range(G)]
+    c.set_profiling(True)  # and once with them, for the record
+    r.step()
+    r.step()
+    dev_ev = np.array([c.group_stripe(j)["stats"]["device_ms"] for j in range(G)])
     c.set_profiling(False)
     c.set_group_serial(False)
     for _ in range(2):
@@ -619,11 +623,12 @@ def stripe_report(r, devices, steps=3):
                             "plan": {"gsip_bound_mode": modes[info[j]["plan"]["bound_mode"]], "batches": info[j]["plan"]["batches"],
                                      "lanes_per_query": info[j]["plan"]["lanes_per_query"]}} for j in range(G)],
             "device_ms_max": float(d.max()), "device_ms_mean": float(d.mean()), "device_ms_max_over_mean": float(d.max() / d.mean()),
+            "device_ms_mean_with_per_launch_events": float(dev_ev.mean()),
             "fanout_us_per_evaluation": float(np.median(fan)), "combine_us_per_evaluation": float(np.median(comb)),
             "fixed_host_us_per_evaluation": float(np.median(fan) + np.median(comb)),
             "ideal_ms_per_step_on_%d_gpus" % G: float(d.max() + 1e-3 * (np.median(fan) + np.median(comb))),
             "concurrent_ms_per_step_here": float(np.median(wall)),
-            "note": "device_ms_alone: HIP-event span of the stripe's pipeline with the stripes run one after the other "
+            "note": "device_ms_alone: HIP-event span (first to last event of the evaluation, svsdf_set_profiling 3: no per-launch events) of the stripe's pipeline with the stripes run one after the other "
                     "(svsdf_set_group_serial) -- on a box with one GPU per stripe that is the stripe's time; fanout = waking "
                     "the per-device host threads + joining them, combine = fixed-order host sum of the partials; "
                     "ideal = slowest stripe + the fixed host cost"}

@@ -462,10 +462,15 @@ int svsdf_set_profiling(svsdf_ctx *ctx, int enable) {
   if (!ctx->subs.empty()) {
     int rc = SVSDF_OK;
     for (svsdf_ctx *s : ctx->subs) { const int r = svsdf_set_profiling(s, enable); if (r && !rc) rc = r; }
-    ctx->profile = enable != 0;
+    ctx->profile = enable != 0 && enable != 3;
+    ctx->profile_span = enable == 3;
     return rc;
   }
-  ctx->profile = enable != 0;
+  // enable == 3 (round 6): the evaluation's device span only (stats.device_ms from the two events every evaluation records
+  // anyway).  The per-launch events of levels 1 / 2 -- two per kernel, ~ 60 per evaluation -- are not free: a 500 k-point
+  // stripe measures 3.85 ms with them and 3.67 ms without (the same evaluation by the host's clock).
+  ctx->profile = enable != 0 && enable != 3;
+  ctx->profile_span = enable == 3;
   if (ctx->host_only) return SVSDF_OK;
   // enable == 2: also run the point batches one after the other (one batch) while profiling, so that every launch's
   // duration is its own cost and not stretched by the kernels of the other batches it normally overlaps with

@@ -159,6 +159,8 @@ struct svsdf_ctx {
   bool have_prev_nactive = false;
   long long wide32_below = 2000, wide16_below = 5000, wide8_below = 40000;  // env SVSDF_WIDE32 / SVSDF_WIDE16 / SVSDF_WIDE8
   bool select_env = false, all_iter_env = false;
+  double scan_delta = 0.002;   // the same band in the scanning bound modes, where the bound is the sample's own table minimum (round 6 sweep, 0 ... 0.01:
+                               // sdHeart / anchor mode - 3.5 % at 0.001 - 0.002 m -- 7 % fewer solves --, C3 / NS / C5 / C2 within +- 0.5 %; 0.01 m until round 5)
   double select_delta = 0.1;  // k_round: solve the samples whose upper bound is within this of the best one first
 
   // per-point / per-sub-query buffers
@@ -187,6 +189,7 @@ struct svsdf_ctx {
 
   // profiling
   bool profile = false;  // per-launch HIP events (env SVSDF_PROFILE=1 or svsdf_set_profiling)
+  bool profile_span = false;     // svsdf_set_profiling(ctx, 3): device_ms only -- the span between the evaluation's first and last event, no per-launch events
   int saved_nbatch = 0;  // svsdf_set_profiling(ctx, 2): the batch split to restore
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;

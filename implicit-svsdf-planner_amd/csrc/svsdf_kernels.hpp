@@ -1540,9 +1540,11 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       // also the points whose first round is still to be opened: k_round FETCH 170 -> 398 MB per C3 evaluation
       const bool ld = PRE && (EAGER ? j < kMaxSlots : (phase_ != kPhaseNew && j < n_pre));
       g_pre[ps] = ld ? gs.sq_sdf[s_] : kUnsolved;
-      t_pre[ps] = ld ? gs.sq_t[s_] : 0.0;
-      th_pre[ps] = ld ? gs.sqth[s_] : 0.0;
       ub_pre[ps] = ld ? gs.sq_ub[s_] : 0.0;
+      // time and angle are only ever used of ONE sample, the arg-max: k_round fetches those two numbers once it is known (a
+      // dependent trip, two values) instead of two more arrays for every sample of every point (round 6; HBM traffic)
+      t_pre[ps] = (EAGER && ld) ? gs.sq_t[s_] : 0.0;
+      th_pre[ps] = (EAGER && ld) ? gs.sqth[s_] : 0.0;
     }
     open = phase_ == kPhaseNew;
     if (!open) {
@@ -1572,7 +1574,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
       double max_g = -100000, real_t = rest_pre, star_th = 0.0;
       if (g > max_g) {
         max_g = g;
-        if constexpr (!PRE) {
+        if constexpr (!PRE || !EAGER) {
           const size_t sb = sample_slot(stride, ia, idx);
           real_t = gs.sq_t[sb]; star_th = gs.sqth[sb];
         } else {

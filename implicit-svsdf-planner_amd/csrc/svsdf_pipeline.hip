@@ -230,9 +230,9 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   }
   // late iterations hold few points and are latency-bound: request every sample there, which
   // avoids supplementary iterations at no cost in time
-  // the seed bound of the scanning modes is tight: a narrow band selects (measured optimum 0.01 m, solve-all from
-  // iteration 7); the chunk bound of the cheap mode needs 0.1 m / iteration 5.  Env values override both.
-  const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
+  // the seed bound of the scanning modes is tight: a narrow band selects (ctx->scan_delta: 0.002 m, solve-all from
+  // iteration 7); the chunk bound of the cheap mode needs 0.1 m / iteration 5.  SVSDF_SELECT_DELTA overrides both.
+  const double sel = (scans && !ctx->select_env) ? ctx->scan_delta : ctx->select_delta;
   const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
   const double delta = (it >= all_it) ? 1e300 : sel;
   const double band_delta = (it >= all_it) ? 1e300 : ctx->select_delta;   // lazy mode: cheap-bound band that gets scanned
@@ -266,7 +266,7 @@ size_t tail_lds_bytes(const svsdf_ctx *ctx, bool poly_lds, bool local) {
 void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const int mode = bound_mode_of(ctx);
   const bool scans = mode != 0;
-  const double sel = (scans && !ctx->select_env) ? 0.01 : ctx->select_delta;
+  const double sel = (scans && !ctx->select_env) ? ctx->scan_delta : ctx->select_delta;
   const int all_it = (scans && !ctx->all_iter_env) ? 7 : ctx->delta_all_iter;
   const int all_after = (ctx->tail_all_after < 0) ? std::max(0, all_it - it0) : ctx->tail_all_after;
   // the active count lives on the device; the grid is sized by what the previous evaluation had there (surplus blocks
@@ -693,6 +693,11 @@ int finish(svsdf_ctx *ctx, bool with_partial) {
   // next evaluation enqueues as many iterations as this one needed (+1); the slow path above
   // covers an underestimate
   if (ctx->adaptive_iters && ctx->tail_iter < 0) ctx->first_iters = std::max(2, std::min((int)st[7] + 1, (int)kMaxIter));
+  if (ctx->profile_span && !ctx->profile) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);
+    ctx->stats.device_ms = ms;
+  }
   if (ctx->profile) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ctx->ev_pool[0], ctx->ev_pool[ctx->e_end]);

@@ -458,7 +458,9 @@ int svsdf_shape_selfcheck(const svsdf_ctx *ctx, double out3[3]);
  * streams; off by default (also env SVSDF_PROFILE=1).  Fills device_ms / solve_ms / solve_ms_sum.
  * enable = 2: additionally runs the point batches one after the other while profiling (a single batch), so that a
  * launch's duration is its own cost rather than stretched by the other batches' kernels it normally overlaps with;
- * enable = 0 restores the split. */
+ * enable = 0 restores the split.
+ * enable = 3: device_ms only -- the span between the first and the last event of the evaluation, which are recorded
+ * anyway; no per-launch events (they cost ~ 5 % of a 500 k-point evaluation), solve_ms / round_ms stay 0. */
 int svsdf_set_profiling(svsdf_ctx *ctx, int enable);
 /* Self-check: number of n equispaced arguments in [lo, hi] for which the kernels' inlined sincos
  * differs by even one bit from the ROCm device library's sincos (must be 0); -1 on error. */
