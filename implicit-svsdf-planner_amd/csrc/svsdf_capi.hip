@@ -442,7 +442,10 @@ int svsdf_debug_site_stats(svsdf_ctx *ctx, unsigned long long out[26]) {
   for (int i = 0; i < 26; ++i) out[i] = 0;
   for (const BatchCtl &b : hc)
     for (const StatSlot &sl : b.stat)
-      for (int i = 0; i < 26; ++i) out[i] += sl.pad[i];
+      for (int i = 0; i < 26; ++i) {
+        if (i == 22 || i == 23) out[i] = std::max(out[i], (unsigned long long)sl.pad[i]);   // maxima over the waves (k_tail)
+        else out[i] += sl.pad[i];
+      }
   return SVSDF_OK;
 }
 #endif

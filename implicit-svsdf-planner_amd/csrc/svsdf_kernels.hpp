@@ -673,9 +673,9 @@ struct Grp {
 // wave-granular dynamic work fetch: every wave takes the next 64/G queries; returns the
 // wave's first query in `wave_base` (wave-uniform) and this lane's query as the result
 template <int G, int M = 1>
-__device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wave_base) {
+__device__ __forceinline__ long long fetch_work(unsigned *cursor, long long &wave_base, int per_wave = M * 64 / G) {
   unsigned base = 0;
-  if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, (unsigned)(M * 64 / G));
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, (unsigned)per_wave);
   base = __builtin_amdgcn_readfirstlane(base);
   wave_base = (long long)base;
   return (long long)base + (long long)((threadIdx.x & 63) / G);
@@ -1216,12 +1216,12 @@ template <int SHAPE, int G, int U>
 __global__ void __launch_bounds__(kBlock, is_polygon<SHAPE>() ? 3 : SVSDF_SOLVE_WAVES)
 k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, QuerySet qs, double *__restrict__ out_sdf,
-        double *__restrict__ out_t, int prune, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh,
+        double *__restrict__ out_t, int prune /* bit 0: exact chunk pruning; bit 1: one query per wave */, BatchCtl *__restrict__ ctl, int work_idx, double cull_thresh,
         const double *__restrict__ rot, double slack_max) {
   extern __shared__ double solve_lds[];
   int n;
   const long long total = qs_total(qs, n);
-  if (total <= 0 || (long long)blockIdx.x * (blockDim.x / G) >= total) return;
+  if (total <= 0 || (long long)blockIdx.x * (((prune & 2) != 0) ? (blockDim.x >> 6) : (blockDim.x / G)) >= total) return;
   const int K = trg->K;
   const int nch = (K + kChunk - 1) / kChunk;
   stage_poly_edges<SHAPE>(sp, solve_lds);
@@ -1249,7 +1249,13 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
   // Work distribution: a wave's FIRST 64 / G queries are its own (wave index: no atomic), the following ones come from
   // the launch's cursor.  (All waves of a launch start together: with a fetch first, their 3000 atomics on one address
   // take ~ 12 ns each, one after the other -- the last wave would start ~ 37 us late, in every launch of the chain.)
-  const long long per_wave = 64 / G;
+  // `prune` bit 1 (round 6; launches of a few hundred queries, i.e. the main solve at the reference's own scale): ONE query per
+  // wave -- the other lane groups stay empty -- so that every descent is "the wave's last open one" from its first pass on and
+  // takes the fused pass (derivative + both signs of the ladder in one step: descend_from_seed) instead of two dependent
+  // steps per pass.  The chip has a wave slot for every query there; the launch is a chain of dependent evaluations.
+  const bool solo = (prune & 2) != 0;
+  prune &= 1;
+  const long long per_wave = solo ? 1 : 64 / G;
   const long long n_static = (long long)gridDim.x * (blockDim.x >> 6) * per_wave;
   for (int guard = 0; guard < (1 << 26); ++guard) {
     long long wave_base, gq;
@@ -1257,13 +1263,13 @@ k_solve(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Po
       wave_base = (long long)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * per_wave;
       gq = wave_base + (long long)((threadIdx.x & 63) / G);
     } else {
-      gq = fetch_work<G>(&ctl->work[work_idx], wave_base) + n_static;
+      gq = fetch_work<G>(&ctl->work[work_idx], wave_base, (int)per_wave) + n_static;
       wave_base += n_static;
     }
     if (wave_base >= total) break;
     double px = 0.0, py = 0.0;
     size_t slot = 0;
-    bool live = gq < total;
+    bool live = gq < total && (long long)((threadIdx.x & 63) / G) < per_wave;
     if (live) live = qs_slot(qs, n, gq, slot);
     if (live) {
       px = qs.qx[slot]; py = qs.qy[slot];
@@ -2432,6 +2438,17 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { ex += __shfl_xor(ex, m, 64); ln += __shfl_xor(ln, m, 64); }
     if (lane == 0 && ex) { StatSlot *ss = stat_slot(ctl->stat); atomicAdd(&ss->pad[20], ex); atomicAdd(&ss->pad[21], ln); }
+    // the launch's SLOWEST wave (round 6: the dependent depth of a reference-scale callback): evaluation-site executions of
+    // one wave -- its seed scans' and its solve passes' -- and the cycles it lived; the maximum over the waves (pad[22], pad[23])
+    unsigned long long steps = ex;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned long long v = sc[i];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      steps += v;
+    }
+    if (lane == 0) { StatSlot *ss = stat_slot(ctl->stat); atomicMax(&ss->pad[22], steps); atomicMax(&ss->pad[23], rc[6]); }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {   // site executions (0 .. 3) and evaluating lanes (4 .. 7), like k_solve

@@ -173,7 +173,10 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
                   double *out_t, BatchCtl *ctl, int work_idx,
                   double cull_thresh = std::numeric_limits<double>::infinity()) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
-  const long long lanes = std::max<long long>(max_queries * G, 64);
+  // a launch of at most one query per SIMD with 32-lane groups (the main solve of a reference-scale cloud): one query per
+  // wave, so that the descents take the fused pass (k_solve, `prune` bit 1)
+  const bool solo = G == 32 && !ctx->G_env && max_queries <= (long long)ctx->n_cu * 4;
+  const long long lanes = std::max<long long>(max_queries * (solo ? 64 : G), 64);
   // Every block stages the pose table + chunk bounds + trajectory into LDS (13 KB at 16 pieces x 2.5 s, 24 KB at 32):
   // with one wave per block that caps the CU at 160 KB / lds waves -- 6 at C3, half of what the kernel's 141 VGPRs
   // allow (3 waves per SIMD) -- so the block grows until LDS no longer binds (measured at C3: 10.7 -> 9.2 ms).
@@ -201,7 +204,7 @@ void launch_solve(svsdf_ctx *ctx, int G, hipStream_t st, const QuerySet &qs, lon
   // (the second, value-based cull runs with the first one: main points of an evaluation that may cull)
   const bool cull2 = std::isfinite(cull_thresh) && ctx->cull2;
   const double *d_rot = d_tk + ctx->K + (ctx->K + kChunk - 1) / kChunk;
-  const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune, ctl, work_idx, cull_thresh,
+  const SolveLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, qs, out_sdf, out_t, ctx->prune | (solo ? 2 : 0), ctl, work_idx, cull_thresh,
                       cull2 ? d_rot : nullptr, ctx->slack_max};
   if (!launch_k_solve(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, G, grid, (unsigned)blk, lds_total, st, a) && ctx->launch_err.empty())
     ctx->launch_err = "k_solve: shape not compiled into this build";
@@ -240,7 +243,9 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   // 18-21 samples: 32 lanes per point (either handles any count).  Iteration 2 (18 samples, still every interior point
   // active: throughput, not latency) also runs faster with 8 lanes and three sample passes per point -- measured round 3,
   // SVSDF_ROUND_LP8_ITERS 2 / 3 / 4 / 6 / all: C3 6.15 / 5.97 / 6.12 / 6.33 / 6.45 ms, NS 7.49 / 7.24 / 7.21 / 7.31 / 7.58
-  const int lp = (it < ctx->round_lp8_iters) ? 8 : 32;
+  // (round 6, re-measured with the balanced launches: 2 / 3 / 4 / 6 iterations -- C3 5.80 / 5.63 / 5.67 / 5.87 ms, C4 6.26 / 5.84 /
+  // 5.88 / 6.00; the lazy mode, whose launches scan few samples per point, gains from a fourth: NS 7.45 / 7.17 / 7.03 / 7.05)
+  const int lp = (it < ctx->round_lp8_iters + (mode == 2 ? 1 : 0)) ? 8 : 32;
   const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, (long long)ctx->n_cu * ctx->round_blocks_per_cu);
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it, delta,
                       band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b, ctx->round_list};
@@ -598,7 +603,7 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
   const int N = ctx->N;
   bool host_written = false;
   if (with_partial) {
-    const unsigned grid = (unsigned)std::min<size_t>((ctx->P + kBlock - 1) / kBlock, 512);
+    const unsigned grid = (unsigned)std::min<size_t>((ctx->P + kBlock - 1) / kBlock, 512);   // (256 / 1024 / 2048 blocks: within 1 %, round 6)
     const size_t plen = 19 * (size_t)N + 1;
     if ((size_t)grid * plen > ctx->block_partials_cap) {
       int rc = dev_alloc(ctx, &ctx->d_block_partials, (size_t)grid * plen);

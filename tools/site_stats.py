@@ -51,5 +51,9 @@ for cfg in cfgs:
     tot = max(out[18], 1)
     print("  k_round wave cycles: " + ", ".join("%s %.3e (%.2f)" % (n, out[12 + i], out[12 + i] / tot) for i, n in enumerate(names)))
     print("  k_round seed-scan evaluation site: executions %d, evaluating lanes %d, occupancy %.3f" % (out[20], out[21], out[21] / max(64 * out[20], 1)))
+    if out[22]:
+        c.set_profiling(True); c.eval_penalty(w["coeffs"], w["T"]); sp = c.stats(); c.set_profiling(False)
+        print("  k_tail's slowest wave: %d dependent evaluation steps (seed scans + solve passes) in %d cycles = %.0f cycles per step; "
+              "k_tail %.1f us of a %.1f us device span (%.0f MHz)" % (out[22], out[23], out[23] / max(out[22], 1), 1e3 * sp["tail_ms"], 1e3 * sp["device_ms"], sp["shader_clock_mhz"]))
     st = c.stats()
     print("  ", {k: st[k] for k in ("solves", "sdf_evals", "scan_evals", "round_scan_evals", "gsip_bound_mode", "batches")})
