@@ -153,6 +153,7 @@ struct svsdf_ctx {
                                          // points; 0 = what one generation of waves holds (24 per CU: 6144 on 256 CUs)
   int tail_all_after = 1 << 30;          // steps of a point inside k_tail after which every sample is requested (-1: like the chain)
   int tail_iter = -1;                    // this evaluation: iteration the tail starts at (-1: none)
+  bool tail_duo = true;                  // k_tail with one point per wave: both half-waves own the point and share its seed scans (env SVSDF_TAIL_DUO=0: off)
   bool tail_local = true;                // k_tail from iteration 0 keeps its points' GSIP state and samples in the wave's LDS (env SVSDF_TAIL_LOCAL=0: global arrays)
   long long prev_nactive[svsdf::kMaxIter] = {}; // active GSIP points per iteration of the previous evaluation, up to its tail
   int prev_tail_iter = -1;

@@ -1499,7 +1499,11 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
                                             double band_delta, double *__restrict__ res_sdf, double *__restrict__ res_t,
                                             double *__restrict__ res_gx, double *__restrict__ res_gy, unsigned &n_scan,
                                             RoundOut<(kMaxSlots + LP - 1) / LP> &out, unsigned short *clist, int clist_on,
-                                            unsigned long long (&rc)[16]) {
+                                            unsigned long long (&rc)[16], int duo = -1) {
+  // duo (k_tail with ONE point per wave, round 6): -1 off; 0 / 1: BOTH half-waves of the wave run this function for the SAME
+  // point (identical state, identical decisions, identical stores) and share its seed scans -- half h takes the scan passes
+  // 2 q + h -- then exchange the results across the halves.  The second half-wave of such a wave had nothing to do; a
+  // reference-scale callback is a chain of dependent steps and a round's 18 - 21 scans were 6 passes of it, now 3.
   constexpr bool FULL = MODE == 1;
   unsigned long long tph = SVSDF_SITE_CLOCK();
   constexpr int NP = (kMaxSlots + LP - 1) / LP;  // sample passes per point
@@ -1787,7 +1791,8 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             nb += __popc(mp[ps]);
           }
           if (nb == 0) break;
-          for (int p = 0; p * SG < nb; ++p) {
+          for (int pq = 0; (duo >= 0 ? 2 * pq : pq) * SG < nb; ++pq) {
+            const int p = duo >= 0 ? 2 * pq + duo : pq;
             const int r = p * SG + sg;          // rank (among the pending samples) this 8-lane sub-group scans
             int rr = r, sps = 0, sl = 0;
             bool found = false;
@@ -1821,6 +1826,14 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
               const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
               const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
               if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
+            }
+          }
+          if (duo >= 0) {   // results of the passes the other half-wave ran (same lane there owns the same sample)
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const double ou = __shfl_xor(ub[ps], 32, 64);
+              const int ok = __shfl_xor(kk[ps], 32, 64);
+              if (pend[ps] && ((myrank[ps] / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; scanned[ps] = true; }
             }
           }
           if (rep == 0 && n_emit > 6) {
@@ -1867,7 +1880,8 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         // and solving the one that matters.
         constexpr int SG = LP / 8;
         const int sg = l >> 3;
-        for (int p = 0; p * SG < n_emit; ++p) {
+        for (int pq = 0; (duo >= 0 ? 2 * pq : pq) * SG < n_emit; ++pq) {
+          const int p = duo >= 0 ? 2 * pq + duo : pq;
           const int sidx = p * SG + sg;             // sample this 8-lane sub-group scans in this pass
           const int slot = sidx / LP;               // uniform over the point's lanes (SG == 1 when NP > 1)
           double sxs = sqx_l[0], sys = sqy_l[0];
@@ -1887,6 +1901,14 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
 #pragma unroll
           for (int ps = 0; ps < NP; ++ps)
             if (valid[ps] && (l + LP * ps) / SG == p) { ub[ps] = rb; kk[ps] = rk; }
+        }
+        if (duo >= 0) {   // the other half-wave scanned the passes of the other parity: lane l there owns the same sample
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) {
+            const double ou = __shfl_xor(ub[ps], 32, 64);
+            const int ok = __shfl_xor(kk[ps], 32, 64);
+            if (valid[ps] && (((l + LP * ps) / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; }
+          }
         }
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
@@ -1929,7 +1951,8 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             nb += __popc(mp[ps]);
           }
           if (nb == 0) break;
-          for (int p = 0; p * SG < nb; ++p) {
+          for (int pq = 0; (duo >= 0 ? 2 * pq : pq) * SG < nb; ++pq) {
+            const int p = duo >= 0 ? 2 * pq + duo : pq;
             const int r = p * SG + sg;          // rank (among the pending samples) this 8-lane sub-group scans
             int rr = r, sps = 0, sl = 0;
             bool found = false;
@@ -1963,6 +1986,14 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
               const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
               const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
               if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
+            }
+          }
+          if (duo >= 0) {   // results of the passes the other half-wave ran (same lane there owns the same sample)
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+              const double ou = __shfl_xor(ub[ps], 32, 64);
+              const int ok = __shfl_xor(kk[ps], 32, 64);
+              if (inband[ps] && !scanned[ps] && ((myrank[ps] / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; scanned[ps] = true; }
             }
           }
           // extend the band to unscanned samples whose cheap bound still reaches the best scanned one
@@ -2321,6 +2352,11 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
   const int *cur = gs.list[it0 & 1] + start;
   const int lane = (int)(threadIdx.x & 63);
   const int h = lane >> 5, l = lane & (LP - 1);
+  // One point per wave (ppw == 1: the launch is a latency chain and has a wave for every point): both half-waves OWN that
+  // point -- same state, same decisions, same stores -- and share its seed scans (round_point's `duo`); only half 0's
+  // requests go to the wave's solve list.  (The scanning bound modes; the cheap mode has no scans to share.)
+  const bool duo = ppw == 1 && MODE != 0 && (clist_on & 8) == 0;
+  const int hs = duo ? 0 : h;   // the half whose slot of the wave-local GSIP state this lane uses
   const unsigned lt_mask = (1u << l) - 1u;
   unsigned n_eval = 0, n_scan = 0, n_solved = 0, n_spec = 0, n_rscan = 0;
   unsigned long long rc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SVSDF_SITE_STATS builds only (8 .. 15: the seed scans' evaluation site)
@@ -2352,12 +2388,12 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
       }
       if (q_next < q_end) {
         const int e = q_next++;
-        if (h == hh) {
+        if (h == hh || duo) {
           a = cur[e]; steps = 0; own = false;
-          if (local && l == 0) {   // the point's state as k_classify left it, into this half's slot of the wave's LDS copy
+          if (local && l == 0 && h == hh) {   // the point's state as k_classify left it, into this half's slot of the wave's LDS copy
             const size_t ia_ = (size_t)a;
-            gl.pt[h] = gs.pt[ia_]; gl.r[h] = gs.r[ia_]; gl.theta0[h] = gs.theta0[ia_]; gl.theta_res[h] = gs.theta_res[ia_];
-            gl.iter[h] = gs.iter[ia_]; gl.nsamp[h] = gs.nsamp[ia_]; gl.phase[h] = gs.phase[ia_]; gl.req[h] = 0u;
+            gl.pt[hs] = gs.pt[ia_]; gl.r[hs] = gs.r[ia_]; gl.theta0[hs] = gs.theta0[ia_]; gl.theta_res[hs] = gs.theta_res[ia_];
+            gl.iter[hs] = gs.iter[ia_]; gl.nsamp[hs] = gs.nsamp[ia_]; gl.phase[hs] = gs.phase[ia_]; gl.req[hs] = 0u;
           }
         }
       }
@@ -2373,16 +2409,16 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     ro.list_me[0] = false; ro.mlist[0] = 0u; ro.n_emit = 0; ro.push_next = false; ro.finished = false;
     if (a >= 0) {
       const double dl = (steps >= all_after) ? 1e300 : delta, bd = (steps >= all_after) ? 1e300 : band_delta;
-      round_point<SHAPE, LP, MODE, true>(sp, pose, chunks, K, nch, px_, py_, ga, stride_a, start, local ? h : a, dl, bd, res_sdf, res_t, res_gx,
-                                   res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc);
+      round_point<SHAPE, LP, MODE, true>(sp, pose, chunks, K, nch, px_, py_, ga, stride_a, start, local ? hs : a, dl, bd, res_sdf, res_t, res_gx,
+                                   res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc, duo ? h : -1);
       ++steps;
       if (ro.n_emit > 0) own = true;
-      if (l == 0) n_emit_tot += ro.n_emit;
+      if (l == 0 && (!duo || h == 0)) n_emit_tot += ro.n_emit;
     }
-    const size_t ia = local ? (size_t)h : (size_t)(a >= 0 ? a : 0);
+    const size_t ia = local ? (size_t)hs : (size_t)(a >= 0 ? a : 0);
     if (ro.finished) a = -1;
-    // ---- the wave's solve list: the selected samples of both halves
-    const unsigned m_mine = (a >= 0) ? ro.mlist[0] : 0u;
+    // ---- the wave's solve list: the selected samples of both halves (duo: of the one point, from half 0)
+    const unsigned m_mine = (a >= 0 && (!duo || h == 0)) ? ro.mlist[0] : 0u;
     const int n0 = __popc((unsigned)__builtin_amdgcn_readlane((int)m_mine, 0));
     const int n1 = __popc((unsigned)__builtin_amdgcn_readlane((int)m_mine, 32));
     const int nq = n0 + n1;
