@@ -2516,6 +2516,64 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
 }
 
 #ifdef SVSDF_API_TU   // shape-independent kernels: compiled once, by svsdf_pipeline.hip
+// The 20 terms one query point adds to the sums (BEO:797-863, grad_cost_p_sw BEO:1031-1066): v[0] cost, v[1..18] gradC of
+// its piece i (x, y, yaw blocks of 6), v[19] the piece's gradT history term.  Returns false (v all zero) for an inactive point.
+__device__ __forceinline__ bool assemble_terms(const TrajL &tr, const double *__restrict__ px_, const double *__restrict__ py_,
+                                               int idx, const double *__restrict__ res_sdf, const double *__restrict__ res_t,
+                                               const double *__restrict__ res_gx, const double *__restrict__ res_gy,
+                                               double safety_hor, double weight_p, double (&v)[20], int &i, int &bad) {
+  const double px = px_[idx], py = py_[idx];
+  const double sdf_value = res_sdf[idx];
+  const double time_star = res_t[idx];
+  double gr0 = res_gx[idx], gr1 = res_gy[idx];
+  if (!(sdf_value == sdf_value) || !(time_star == time_star) || !(gr0 == gr0) || !(gr1 == gr1)) ++bad;
+  double sdf_cost = -1.0, sdf_out_grad = 0.0;
+  smoothed_l1(safety_hor - sdf_value, 0.01, sdf_cost, sdf_out_grad);
+  if (!(sdf_cost > 0)) return false;
+  double s1;
+  i = locate_local(tr, time_star, 0, s1);
+  const double *c = tr.c + i * 18;
+  const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+  const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  double pos[3], vel[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    double p = 0.0, vv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { p += c[k * 3 + d] * beta0[k]; vv += c[k * 3 + d] * beta1[k]; }
+    pos[d] = p; vel[d] = vv;
+  }
+  const double yaw = pos[2];
+  double sy, cy;
+  sincos(yaw, &sy, &cy);
+  if (sdf_value < 0) {  // BEO:832
+    const double gx = cy * gr0 + sy * gr1;
+    const double gy = (-sy) * gr0 + cy * gr1;
+    gr0 = gx; gr1 = gy;
+  }
+  // grad_cost_p_sw (BEO:1031-1066) with St = I
+  const double mrx = (-cy) * gr0 + (sy) * gr1;
+  const double mry = (-sy) * gr0 + (-cy) * gr1;
+  const double sgx = -sdf_out_grad * mrx, sgy = -sdf_out_grad * mry;
+  const double dx = px - pos[0], dy = py - pos[1];
+  const double v0 = (-sy) * dx + (cy) * dy;
+  const double v1 = (-cy) * dx + (-sy) * dy;
+  const double grad_yaw = (-sdf_out_grad * gr0) * v0 + (-sdf_out_grad * gr1) * v1;
+  const double gPx = weight_p * sgx, gPy = weight_p * sgy, gYaw = weight_p * grad_yaw;
+  v[0] = weight_p * sdf_cost;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { v[1 + k] = beta0[k] * gPx; v[7 + k] = beta0[k] * gPy; v[13 + k] = beta0[k] * gYaw; }
+  v[19] = -((gPx * vel[0] + gPy * vel[1]) + gYaw * vel[2]);
+  return true;
+}
+
+// doubles of LDS behind the trajectory that the one-block form of the assembly uses: the sums [plen], the terms of the
+// block's points term-major [20][kBlock], and per wave the lane masks of the active points and of every piece [N + 1] (64-bit)
+__host__ __device__ __forceinline__ size_t assemble_small_doubles(int N) {
+  return (size_t)(19 * N + 1) + 20 * (size_t)kBlock + (size_t)(kBlock / 64) * (size_t)(N + 1);
+}
+
 __device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, const double *__restrict__ px_,
            const double *__restrict__ py_, int P, const double *__restrict__ res_sdf,
            const double *__restrict__ res_t, const double *__restrict__ res_gx,
@@ -2532,9 +2590,56 @@ __device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, c
   const int plen = 19 * N + 1;
   constexpr int kWaves = kBlock / 64;
   double *acc_all = asm_lds + traj_lds_doubles(N);
+  const int lane = (int)(threadIdx.x & 63);
+  if (keep_in_lds) {
+    // One block holds the whole cloud (P <= kBlock: the reference's own scale, 101 .. 139 points on its demo maps; round 6).
+    // A wave of such a cloud holds a dozen DIFFERENT pieces and the walk below costs 20 six-step butterflies for each of them,
+    // one wave per SIMD, nothing to hide the exchange latency behind: 25 of the 29 us this launch took in a 340 - 400 us
+    // callback.  Here every active point leaves its 20 terms in LDS (term-major: lane-contiguous, no bank conflicts) and the
+    // waves leave one lane mask per piece; then ONE THREAD PER ENTRY of the result adds the terms of its piece's points in
+    // ascending point index -- the order of the reference's serial loop (BEO:797-863) and of the oracle.  A handful of
+    // dependent additions per entry instead of 120 exchange steps per piece.  (Fixed order: bit-reproducible like the
+    // butterflies; the rounding of the sums differs from theirs in the last bits, as any two orders do.)
+    double *vals = acc_all + plen;
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(vals + 20 * (size_t)kBlock);   // [kWaves][N + 1], entry N: active
+    const int idx = (int)threadIdx.x, wv = (int)(threadIdx.x >> 6);
+    int i = -1, bad = 0;
+    double v[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) v[q] = 0.0;
+    const bool act = idx < P && assemble_terms(tr, px_, py_, idx, res_sdf, res_t, res_gx, res_gy, safety_hor, weight_p, v, i, bad);
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < 20; ++q) vals[(size_t)q * kBlock + threadIdx.x] = v[q];
+    }
+    for (int p0 = 0; p0 <= N; ++p0) {
+      const unsigned long long mk = __ballot(act && (p0 == N || i == p0));
+      if (lane == 0) masks[(size_t)wv * (N + 1) + p0] = mk;
+    }
+    if (bad) atomicAdd(nonfinite, bad);
+    __syncthreads();
+    for (int e = threadIdx.x; e < plen; e += blockDim.x) {
+      // entry e <-> (piece, term): e = 0 the cost (all pieces), 1 + blk 6 N + 6 i + r gradC, 1 + 18 N + i the gradT history
+      int pc = N, q = 0;
+      if (e > 18 * N) { pc = e - 1 - 18 * N; q = 19; }
+      else if (e > 0) { const int blk = (e - 1) / (6 * N), rem = (e - 1) % (6 * N); pc = rem / 6; q = 1 + blk * 6 + rem % 6; }
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        unsigned long long m = masks[(size_t)w * (N + 1) + pc];
+        while (m) {
+          const int ln = __ffsll((long long)m) - 1;
+          s += vals[(size_t)q * kBlock + w * 64 + ln];
+          m &= m - 1ull;
+        }
+      }
+      block_partials[(size_t)e] = s;   // (gridDim.x == 1)
+      acc_all[e] = 0.0 + s;            // k_final's sum of this entry over one block partial, for k_reduce
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < kWaves * plen; e += blockDim.x) acc_all[e] = 0.0;
   __syncthreads();
-  const int lane = (int)(threadIdx.x & 63);
   double *acc = acc_all + (size_t)(threadIdx.x >> 6) * plen;
   int bad = 0;
   for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {
@@ -2544,53 +2649,7 @@ __device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, c
     double v[20];
 #pragma unroll
     for (int q = 0; q < 20; ++q) v[q] = 0.0;
-    if (idx < P) {
-      const double px = px_[idx], py = py_[idx];
-      const double sdf_value = res_sdf[idx];
-      const double time_star = res_t[idx];
-      double gr0 = res_gx[idx], gr1 = res_gy[idx];
-      if (!(sdf_value == sdf_value) || !(time_star == time_star) || !(gr0 == gr0) || !(gr1 == gr1)) ++bad;
-      double sdf_cost = -1.0, sdf_out_grad = 0.0;
-      smoothed_l1(safety_hor - sdf_value, 0.01, sdf_cost, sdf_out_grad);
-      if (sdf_cost > 0) {
-        double s1;
-        i = locate_local(tr, time_star, 0, s1);
-        const double *c = tr.c + i * 18;
-        const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-        const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
-        const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
-        double pos[3], vel[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          double p = 0.0, vv = 0.0;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { p += c[k * 3 + d] * beta0[k]; vv += c[k * 3 + d] * beta1[k]; }
-          pos[d] = p; vel[d] = vv;
-        }
-        const double yaw = pos[2];
-        double sy, cy;
-        sincos(yaw, &sy, &cy);
-        if (sdf_value < 0) {  // BEO:832
-          const double gx = cy * gr0 + sy * gr1;
-          const double gy = (-sy) * gr0 + cy * gr1;
-          gr0 = gx; gr1 = gy;
-        }
-        // grad_cost_p_sw (BEO:1031-1066) with St = I
-        const double mrx = (-cy) * gr0 + (sy) * gr1;
-        const double mry = (-sy) * gr0 + (-cy) * gr1;
-        const double sgx = -sdf_out_grad * mrx, sgy = -sdf_out_grad * mry;
-        const double dx = px - pos[0], dy = py - pos[1];
-        const double v0 = (-sy) * dx + (cy) * dy;
-        const double v1 = (-cy) * dx + (-sy) * dy;
-        const double grad_yaw = (-sdf_out_grad * gr0) * v0 + (-sdf_out_grad * gr1) * v1;
-        const double gPx = weight_p * sgx, gPy = weight_p * sgy, gYaw = weight_p * grad_yaw;
-        v[0] = weight_p * sdf_cost;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { v[1 + k] = beta0[k] * gPx; v[7 + k] = beta0[k] * gPy; v[13 + k] = beta0[k] * gYaw; }
-        v[19] = -((gPx * vel[0] + gPy * vel[1]) + gYaw * vel[2]);
-        act = true;
-      }
-    }
+    if (idx < P) act = assemble_terms(tr, px_, py_, idx, res_sdf, res_t, res_gx, res_gy, safety_hor, weight_p, v, i, bad);
     unsigned long long m = __ballot(act);
     while (m) {
       const int src = __ffsll((long long)m) - 1;
@@ -2624,7 +2683,6 @@ __device__ __forceinline__ void assemble_body(const TrajDev *__restrict__ trg, c
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += acc_all[(size_t)w * plen + e];
     block_partials[(size_t)e * gridDim.x + blockIdx.x] = s;
-    if (keep_in_lds) acc_all[e] = 0.0 + s;   // (a one-block grid: k_final's sum of this entry, for k_reduce -- in place of row 0)
   }
 }
 

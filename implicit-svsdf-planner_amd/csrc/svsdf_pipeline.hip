@@ -610,7 +610,8 @@ int reduce_and_read(svsdf_ctx *ctx, bool with_partial) {
       if (rc) return rc;
       ctx->block_partials_cap = (size_t)grid * plen;
     }
-    const size_t lds = ((size_t)traj_lds_doubles(N) + (kBlock / 64) * plen) * sizeof(double);  // one accumulator row per wave
+    // one accumulator row per wave; a cloud that fits ONE block keeps its points' terms in LDS instead (assemble_body)
+    const size_t lds = ((size_t)traj_lds_doubles(N) + std::max<size_t>((kBlock / 64) * plen, grid == 1 ? svsdf::assemble_small_doubles(N) : 0)) * sizeof(double);
     if (lds > ctx->lds_limit)   // (98 KB at 128 pieces: fits gfx950's 160 KB; a clear error instead of a raw launch failure elsewhere)
       return fail(ctx, SVSDF_ERR_INVALID, "trajectory too long for the reduction's LDS accumulator rows (" + std::to_string(lds) + " B of " +
                   std::to_string(ctx->lds_limit) + " B per block)");
