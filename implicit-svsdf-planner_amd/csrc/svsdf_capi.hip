@@ -205,6 +205,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   }
   if (const char *e = std::getenv("SVSDF_CULL")) { ctx->cull = std::atoi(e) != 0; ctx->cull2 = std::atoi(e) >= 2; }   // 0 none, 1 circle bound only, 2 both (default)
   if (const char *e = std::getenv("SVSDF_ROUND_BPC")) ctx->round_blocks_per_cu = std::max(1, std::min(std::atoi(e), 16));
+  if (const char *e = std::getenv("SVSDF_SCAN_ANCHORS")) ctx->scan_anchors = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL_DUO")) ctx->tail_duo = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL_LOCAL")) ctx->tail_local = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL")) ctx->tail_mode = (std::string(e) == "off") ? -2 : (std::string(e) == "auto") ? -1 : std::max(0, std::atoi(e));

@@ -135,6 +135,7 @@ struct svsdf_ctx {
   double ub_ratio = 0.0;       // GSIP solves / GSIP samples of the deciding (cheap-bound) evaluation
   double ub_threshold = 0.5;   // env SVSDF_UB_RATIO (analytic shapes; Polygon 0.2)
   bool ub_thr_env = false;
+  bool scan_anchors = true;    // seed scans of k_round / k_tail evaluate the anchors of the circle test's survivors first (ChunkAnchor; env SVSDF_SCAN_ANCHORS=0: off; needs lipschitz_ok; same results)
   int round_list = 3;          // k_round: per-point candidate-chunk lists (env SVSDF_ROUND_LIST: bit 0 scans, bit 1 cheap bound use them; 0: all chunks; same results)
   bool cull = true;            // exact cull of provably inactive points in the main solve (env SVSDF_CULL=0 disables)
   bool cull_ok = false;        // this trajectory: duration not stale, slack table valid

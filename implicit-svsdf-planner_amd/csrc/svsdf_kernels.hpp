@@ -67,6 +67,15 @@ struct Pose { double x, y, cs, sn; };
 // that  sdf(sample) >= |p - c| - rb  for every sample of the chunk.
 constexpr int kChunk = 8;
 struct Chunk { double cx, cy, rb, slack; };  // slack: continuous-path allowance V_c * h for the exact cull (host)
+// Anchor of a chunk (round 6; k_prep writes the table behind the nch chunk records, same buffer): the pose `ka` of the chunk
+// whose largest distance to the chunk's other poses is smallest.  A shape SDF is 1-Lipschitz, and for a pose k and the anchor
+// a of one chunk the body-frame images of a world point q differ by  R_k^T (x_a - x_k) + (R_k - R_a)^T (q - x_a),  so
+//   sdf_k(q) >= sdf_a(q) - (max_k |x_k - x_a| + max_k |R_k - R_a| |q - x_a|)        (|R_k - R_a| = 2 |sin((yaw_k - yaw_a) / 2)|)
+// adx = the first maximum (with its rounding allowance), rot2 = the square of the second (likewise).
+struct ChunkAnchor { double adx, rot2; int ka, pad_; double pad2_; };   // 32 bytes like Chunk
+#ifndef SVSDF_ANCHOR_MIN
+#define SVSDF_ANCHOR_MIN 3   // circle survivors from which a seed scan evaluates their anchors first (below: the chunks themselves)
+#endif
 
 constexpr int kStatSlots = 32;
 #ifdef SVSDF_SITE_STATS
@@ -500,6 +509,24 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     Chunk ch;
     ch.cx = cx; ch.cy = cy; ch.rb = r * (1.0 + 1e-12) + r_bound + 1e-9; ch.slack = slack[c];
     chunks[c] = ch;
+    // the chunk's anchor (ChunkAnchor): the pose with the smallest largest distance to the others, first one wins ties
+    int ka = k0;
+    double adx = 1e300;
+    for (int a = k0; a < k1; ++a) {
+      double m = 0.0;
+      for (int k = k0; k < k1; ++k) m = fmax(m, norm2(pose[k].x - pose[a].x, pose[k].y - pose[a].y));
+      if (m < adx) { adx = m; ka = a; }
+    }
+    double rot2 = 0.0;
+    for (int k = k0; k < k1; ++k) {
+      const double dc = pose[k].cs - pose[ka].cs, ds = pose[k].sn - pose[ka].sn;
+      rot2 = fmax(rot2, dc * dc + ds * ds);
+    }
+    ChunkAnchor an;
+    an.adx = adx * (1.0 + 1e-9) + 2e-9;    // (+ the absolute allowance of the test: values are compared as computed)
+    an.rot2 = rot2 * (1.0 + 1e-8) + 1e-18;
+    an.ka = ka; an.pad_ = 0; an.pad2_ = 0.0;
+    reinterpret_cast<ChunkAnchor *>(chunks + nch)[c] = an;
   }
 }
 
@@ -697,7 +724,7 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
                                             double &best_d, int &best_k, bool &culled, unsigned &n_scan,
                                             const unsigned short *clist = nullptr, int ncl = -1,
                                             unsigned long long *sc = nullptr, const double *__restrict__ rot = nullptr,
-                                            double slack_max = 0.0) {
+                                            double slack_max = 0.0, const ChunkAnchor *__restrict__ anch = nullptr) {
   const int li = Grp<G>::li();
   best_d = 1e9;   // min_dis initial value (SWM:545)
   best_k = 0x7fffffff;
@@ -763,6 +790,75 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
     const int c0 = c_loc;
     eval_chunk(c0);
     int j = 0;
+    if constexpr (G == 8) {
+      // Anchored walk (round 6; `anch`: the chunks' anchor table, null = off).  The circle test |q - c| - rb knows a chunk only
+      // by its bounding circle plus the shape's circumradius: for a large or thin shape (sdHeart: rb ~ 5 m) a scan evaluated 8
+      // chunks where 2 - 3 hold a pose that matters.  Here the survivors of the circle test (against the first chunk's minimum)
+      // FIRST get their anchor pose evaluated, eight chunks per step -- each a real table value, so it lowers the running
+      // minimum at once -- and a chunk is then evaluated in full only if the anchored bound (ChunkAnchor) also reaches the
+      // running minimum.  CPU study (tools/experiments/anchor_chunk_bound.py): 8.1 -> 4.4 steps per scan at C4, 5.0 -> 3.9 at
+      // C3; with fewer than SVSDF_ANCHOR_MIN survivors the anchors cost more steps than they save (star: 2.4 -> 3.0) and the
+      // plain walk runs.  A chunk is skipped only when a lower bound of ALL its poses lies strictly above a value already
+      // found: the (value, earliest index) minimum is the same.
+      if (anch != nullptr && nl <= 64) {
+        unsigned long long M = 0ull;   // bit j <-> list position j survives the circle test
+        for (int jb = 0; jb < nl; jb += 8) {
+          const int jj = jb + li;
+          bool need = false;
+          if (jj < nl) {
+            const int cc = chunk_at(jj);
+            if (cc != c0) {
+              const Chunk ch = chunks[cc];
+              const double ex = px - ch.cx, ey = py - ch.cy;
+              const double t = best_d + ch.rb;
+              need = (t >= 0.0) && (ex * ex + ey * ey <= t * t * (1.0 + 1e-12));
+            }
+          }
+          M |= (unsigned long long)Grp<G>::ballot(need) << jb;
+        }
+        if (__popcll(M) >= SVSDF_ANCHOR_MIN) {
+          // lane li takes the survivor of rank li (ascending list position); survivors beyond the eighth -- rare -- are left
+          // to the plain walk below, which resumes behind the eighth one (and tests them against the minimum found by then)
+          unsigned long long m = M;
+          for (int q = 0; q < li; ++q) m &= m - 1ull;
+          for (int q = 0; q < 8; ++q) M &= M - 1ull;
+          j = M ? (__ffsll((long long)M) - 1) : nl;
+          bool nf = m != 0ull;
+          const int cc = chunk_at(nf ? (__ffsll((long long)m) - 1) : 0);
+          double lba = 1e300, da = 1e300;   // lba: lower bound of every pose of chunk cc from its anchor
+          if (sc) SVSDF_SITE(sc, 0, nf);
+          if (nf) {
+            const ChunkAnchor an = anch[cc];
+            const int ka = an.ka;
+            const Pose p = pose[ka];
+            const double ax = px - p.x, ay = py - p.y;
+            // (the allowance before the evaluation: one number is live across it instead of the anchor's record and position)
+            const double allow = an.adx + sqrt(an.rot2 * (ax * ax + ay * ay)) * (1.0 + 1e-12);
+            da = sdf_from_pose<SHAPE>(sp, p, px, py);
+            ++n_scan;
+            if (da < d_lane || (da == d_lane && ka < k_lane)) { d_lane = da; k_lane = ka; }
+            lba = da - allow;
+          }
+          da = dmin(da, Grp<G>::template xchg<0>(da));
+          da = dmin(da, Grp<G>::template xchg<1>(da));
+          da = dmin(da, Grp<G>::template xchg<2>(da));
+          if (da < best_d) best_d = da;
+          for (;;) {
+            if (nf) {
+              const Chunk ch = chunks[cc];
+              const double ex = px - ch.cx, ey = py - ch.cy;
+              const double t = best_d + ch.rb;
+              nf = !(lba > best_d) && (t >= 0.0) && (ex * ex + ey * ey <= t * t * (1.0 + 1e-12));
+            }
+            const unsigned mm = Grp<G>::ballot(nf);
+            if (mm == 0u) break;
+            const int first = __ffs(mm) - 1;
+            eval_chunk(__shfl(cc, first, G));
+            if (li == first) nf = false;
+          }
+        }
+      }
+    }
     while (j < nl) {
       const int jj = j + li;
       bool need = false;
@@ -1499,7 +1595,20 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
                                             double band_delta, double *__restrict__ res_sdf, double *__restrict__ res_t,
                                             double *__restrict__ res_gx, double *__restrict__ res_gy, unsigned &n_scan,
                                             RoundOut<(kMaxSlots + LP - 1) / LP> &out, unsigned short *clist, int clist_on,
-                                            unsigned long long (&rc)[16], int duo = -1) {
+                                            unsigned long long (&rc)[16], int duo = -1, const ChunkAnchor *__restrict__ anch_ = nullptr) {
+  // (the lazy mode scans few samples, and picks itself where the circle bounds are already good -- star: the anchored walk is
+  // compiled into the full and anchor modes only; in the lazy kernels its registers cost a wave per SIMD for nothing)
+#ifdef SVSDF_NO_SCAN_ANCHORS
+  const ChunkAnchor *__restrict__ anch = nullptr; (void)anch_;
+#else
+#ifdef SVSDF_ANCHORS_NOT_LP8_M3
+  const ChunkAnchor *__restrict__ anch = (MODE == 1 || (MODE == 3 && LP == 32)) ? anch_ : nullptr;
+#else
+  // (and not for the Polygon: its SDF is several times an analytic shape's code, and a fourth inlined copy of it -- the anchor
+  // site -- cost C5 8 % with the walk switched off and 12 % with it on: 17.7 -> 19.1 / 19.9 ms)
+  const ChunkAnchor *__restrict__ anch = ((MODE == 1 || MODE == 3) && !is_polygon<SHAPE>()) ? anch_ : nullptr;
+#endif
+#endif
   // duo (k_tail with ONE point per wave, round 6): -1 off; 0 / 1: BOTH half-waves of the wave run this function for the SAME
   // point (identical state, identical decisions, identical stores) and share its seed scans -- half h takes the scan passes
   // 2 q + h -- then exchange the results across the halves.  The second half-wave of such a wave had nothing to do; a
@@ -1782,14 +1891,20 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         double u2 = -1e300;   // best scanned bound so far
         for (int rep = 0; rep < 8; ++rep) {
           unsigned mp[NP];
-          int myrank[NP];
           int nb = 0;
 #pragma unroll
           for (int ps = 0; ps < NP; ++ps) {
             mp[ps] = ballot_g(pend[ps]);
-            myrank[ps] = nb + __popc(mp[ps] & lt_mask);
             nb += __popc(mp[ps]);
           }
+          // rank of this lane's sample of pass ps among the pending ones (recomputed where it is used: three registers less
+          // across the scans in the kernels with three sample passes per lane)
+          auto myrank = [&](int ps) -> int {
+            int rk_ = __popc(mp[ps] & lt_mask);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) if (q < ps) rk_ += __popc(mp[q]);
+            return rk_;
+          };
           if (nb == 0) break;
           for (int pq = 0; (duo >= 0 ? 2 * pq : pq) * SG < nb; ++pq) {
             const int p = duo >= 0 ? 2 * pq + duo : pq;
@@ -1818,13 +1933,13 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             int bk = 0;
             if (found) {
               bool cu;
-              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8);
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8, nullptr, 0.0, anch);
             }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
-              const bool mine = pend[ps] && (myrank[ps] / SG == p);
-              const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
-              const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
+              const bool mine = pend[ps] && (myrank(ps) / SG == p);
+              const double rb = __shfl(bd, (myrank(ps) % SG) * 8, LP);
+              const int rk = __shfl(bk, (myrank(ps) % SG) * 8, LP);
               if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
             }
           }
@@ -1833,7 +1948,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             for (int ps = 0; ps < NP; ++ps) {
               const double ou = __shfl_xor(ub[ps], 32, 64);
               const int ok = __shfl_xor(kk[ps], 32, 64);
-              if (pend[ps] && ((myrank[ps] / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; scanned[ps] = true; }
+              if (pend[ps] && ((myrank(ps) / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; scanned[ps] = true; }
             }
           }
           if (rep == 0 && n_emit > 6) {
@@ -1893,7 +2008,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
           int bk = 0;
           if (sidx < n_emit) {
             bool cu;
-            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8);
+            scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8, nullptr, 0.0, anch);
           }
           // hand the result to the lane that owns the sample: sub-group (j % SG) scanned sample j in pass j / SG
           const double rb = __shfl(bd, (l % SG) * 8, LP);
@@ -1942,14 +2057,18 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
         double u2 = -1e300;   // best scanned bound so far
         for (int rep = 0; rep < SVSDF_LAZY_REPS; ++rep) {
           unsigned mp[NP];
-          int myrank[NP];
           int nb = 0;
 #pragma unroll
           for (int ps = 0; ps < NP; ++ps) {
             mp[ps] = ballot_g(inband[ps] && !scanned[ps]);
-            myrank[ps] = nb + __popc(mp[ps] & lt_mask);
             nb += __popc(mp[ps]);
           }
+          auto myrank = [&](int ps) -> int {   // (see the anchor mode above)
+            int rk_ = __popc(mp[ps] & lt_mask);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) if (q < ps) rk_ += __popc(mp[q]);
+            return rk_;
+          };
           if (nb == 0) break;
           for (int pq = 0; (duo >= 0 ? 2 * pq : pq) * SG < nb; ++pq) {
             const int p = duo >= 0 ? 2 * pq + duo : pq;
@@ -1978,13 +2097,13 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             int bk = 0;
             if (found) {
               bool cu;
-              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8);
+              scan_layer1<SHAPE, 8, true>(sp, pose, chunks, K, nch, qx, qy, 1, __longlong_as_double(0x7ff0000000000000ll), bd, bk, cu, n_scan, clist, (clist_on & 1) ? ncl : -1, rc + 8, nullptr, 0.0, anch);
             }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
-              const bool mine = inband[ps] && !scanned[ps] && (myrank[ps] / SG == p);
-              const double rb = __shfl(bd, (myrank[ps] % SG) * 8, LP);
-              const int rk = __shfl(bk, (myrank[ps] % SG) * 8, LP);
+              const bool mine = inband[ps] && !scanned[ps] && (myrank(ps) / SG == p);
+              const double rb = __shfl(bd, (myrank(ps) % SG) * 8, LP);
+              const int rk = __shfl(bk, (myrank(ps) % SG) * 8, LP);
               if (mine) { ub[ps] = rb; kk[ps] = rk; scanned[ps] = true; }
             }
           }
@@ -1993,7 +2112,7 @@ __device__ __forceinline__ void round_point(const ShapeParams &sp, const Pose *p
             for (int ps = 0; ps < NP; ++ps) {
               const double ou = __shfl_xor(ub[ps], 32, 64);
               const int ok = __shfl_xor(kk[ps], 32, 64);
-              if (inband[ps] && !scanned[ps] && ((myrank[ps] / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; scanned[ps] = true; }
+              if (inband[ps] && !scanned[ps] && ((myrank(ps) / SG) & 1) != duo) { ub[ps] = ou; kk[ps] = ok; scanned[ps] = true; }
             }
           }
           // extend the band to unscanned samples whose cheap bound still reaches the best scanned one
@@ -2060,6 +2179,13 @@ constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
 // MODE: 0 cheap bound (nearest chunk), 1 full (every new sample scanned), 2 lazy (cheap bound for all, the sample's own
 // table scan only for those within `band_delta` of the best cheap bound -- the ones the cheap mode would solve), 3 anchor
 // (every third sample scanned, the others only if their Lipschitz bound from the anchors reaches the selection band)
+#ifndef SVSDF_ROUND_M3_WAVES
+#define SVSDF_ROUND_M3_WAVES 1   // (round 6) 4: hold k_round<analytic shape, 8 lanes, anchor mode> at 128 VGPRs = 4 waves per SIMD -- with the anchored
+                                 // walk it needs 134 (3 waves).  The allocator then spills ONE VGPR (8 - 20 B of scratch) and C4 gains 2.1 - 2.5 %
+                                 // (500 k: 3.43 -> 3.36 ms, 4 M: 19.41 -> 18.93), but tests/test_gpu_plan.py::test_fused_tail_is_invisible aborts
+                                 // with a device fault, like SVSDF_ROUND_WAVES=5 did: these kernels keep ~ 200 spilled SGPRs in VGPR lanes, and a
+                                 // VGPR spilled to scratch under a partial EXEC mask is the suspect.  No variant of k_round with scratch is shipped.
+#endif
 #ifndef SVSDF_ROUND_WAVES
 #define SVSDF_ROUND_WAVES 1   // waves per SIMD the register allocation of k_round aims at (1: whatever its registers allow = 4).  Round 6
                               // measured 5 (96 VGPRs, 68 - 190 B of scratch per lane): + 1 ... 4 % -- and k_round<star, 8, anchor> then faulted
@@ -2067,7 +2193,7 @@ constexpr int kRoundBlock = SVSDF_ROUND_BLOCK;
                               // waves, i.e. without scratch, and not understood): no spilling variant of this kernel is shipped
 #endif
 template <int SHAPE, int LP, int MODE>
-__global__ void __launch_bounds__(kRoundBlock, SVSDF_ROUND_WAVES)
+__global__ void __launch_bounds__(kRoundBlock, (LP == 8 && MODE == 3 && SVSDF_ROUND_M3_WAVES > 1 && !is_polygon<SHAPE>()) ? SVSDF_ROUND_M3_WAVES : SVSDF_ROUND_WAVES)
 k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
         const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_,
         const double *__restrict__ py_, GsipState gs, size_t stride, int it, double delta, double band_delta,
@@ -2140,7 +2266,8 @@ k_round(const TrajDev *__restrict__ trg, const Pose *__restrict__ pose_g,
     if (active) {
       a = cur[e];
       round_point<SHAPE, LP, MODE>(sp, pose, chunks, K, nch, px_, py_, gs, stride, start, a, delta, band_delta, res_sdf,
-                                   res_t, res_gx, res_gy, n_scan, ro, s_clist + (size_t)hw * kMaxCand, clist_on, rc);
+                                   res_t, res_gx, res_gy, n_scan, ro, s_clist + (size_t)hw * kMaxCand, clist_on, rc, -1,
+                                   (clist_on & 16) ? reinterpret_cast<const ChunkAnchor *>(chunks_g + nch) : nullptr);
     }
     if (l == 0) {
       const int ent = nbuf * PPB + hw;
@@ -2410,7 +2537,8 @@ k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pos
     if (a >= 0) {
       const double dl = (steps >= all_after) ? 1e300 : delta, bd = (steps >= all_after) ? 1e300 : band_delta;
       round_point<SHAPE, LP, MODE, true>(sp, pose, chunks, K, nch, px_, py_, ga, stride_a, start, local ? hs : a, dl, bd, res_sdf, res_t, res_gx,
-                                   res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc, duo ? h : -1);
+                                   res_gy, n_rscan, ro, clist_w + (size_t)h * kMaxCand, clist_on, rc, duo ? h : -1,
+                                   (clist_on & 16) ? reinterpret_cast<const ChunkAnchor *>(chunks_g + nch) : nullptr);
       ++steps;
       if (ro.n_emit > 0) own = true;
       if (l == 0 && (!duo || h == 0)) n_emit_tot += ro.n_emit;

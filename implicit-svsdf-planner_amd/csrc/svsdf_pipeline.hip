@@ -248,7 +248,7 @@ void launch_round(svsdf_ctx *ctx, hipStream_t st, int b, int it) {
   const int lp = (it < ctx->round_lp8_iters + (mode == 2 ? 1 : 0)) ? 8 : 32;
   const unsigned grid = (unsigned)std::min<long long>((pts * lp + kRoundBlock - 1) / kRoundBlock, (long long)ctx->n_cu * ctx->round_blocks_per_cu);
   const RoundLaunch a{ctx->d_traj, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it, delta,
-                      band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b, ctx->round_list};
+                      band_delta, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy, ctx->d_ctl + b, ctx->round_list | ((ctx->scan_anchors && ctx->lipschitz_ok) ? 16 : 0)};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_round(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, lp, mode, grid, lds, st, a) && ctx->launch_err.empty())
@@ -302,7 +302,7 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const TailLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it0, mode,
                      sel, ctx->select_delta, all_after, ppw, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                     ctx->d_ctl + b, ctx->round_list | (local ? 4 : 0) | (ctx->tail_duo ? 0 : 8), ctx->prune};
+                     ctx->d_ctl + b, ctx->round_list | (local ? 4 : 0) | (ctx->tail_duo ? 0 : 8) | ((ctx->scan_anchors && ctx->lipschitz_ok) ? 16 : 0), ctx->prune};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_tail(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a) && ctx->launch_err.empty())
@@ -377,7 +377,7 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bo
   if (K > ctx->pose_cap) {
     int rc = dev_alloc(ctx, &ctx->d_pose, K + 1024);
     if (rc) return rc;
-    rc = dev_alloc(ctx, &ctx->d_chunks, (K + 1024) / kChunk + 2);
+    rc = dev_alloc(ctx, &ctx->d_chunks, 2 * ((K + 1024) / kChunk + 2));   // chunk records, then the anchor table (ChunkAnchor, k_prep)
     if (rc) return rc;
     ctx->pose_cap = K + 1024;
   }
