@@ -509,19 +509,39 @@ __global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, 
     Chunk ch;
     ch.cx = cx; ch.cy = cy; ch.rb = r * (1.0 + 1e-12) + r_bound + 1e-9; ch.slack = slack[c];
     chunks[c] = ch;
-    // the chunk's anchor (ChunkAnchor): the pose with the smallest largest distance to the others, first one wins ties
-    int ka = k0;
-    double adx = 1e300;
-    for (int a = k0; a < k1; ++a) {
-      double m = 0.0;
-      for (int k = k0; k < k1; ++k) m = fmax(m, norm2(pose[k].x - pose[a].x, pose[k].y - pose[a].y));
-      if (m < adx) { adx = m; ka = a; }
+    // the chunk's anchor (ChunkAnchor): the pose with the smallest largest distance to the others, first one wins ties.
+    // The chunk's poses go to registers first (a short chunk repeats its last pose: no distance changes) and everything is
+    // unrolled, squared distances, one root: the first form -- 64 correctly rounded roots on poses re-read from global
+    // memory -- doubled this one-block kernel's time (10 -> 20 us of a 350 us reference-scale callback).
+    double ax_[kChunk], ay_[kChunk], ac_[kChunk], as_[kChunk];
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) {
+      const Pose pq = pose[(k0 + q < k1) ? k0 + q : k1 - 1];
+      ax_[q] = pq.x; ay_[q] = pq.y; ac_[q] = pq.cs; as_[q] = pq.sn;
     }
-    double rot2 = 0.0;
-    for (int k = k0; k < k1; ++k) {
-      const double dc = pose[k].cs - pose[ka].cs, ds = pose[k].sn - pose[ka].sn;
+    int qa = 0;
+    double adx2 = 1e300;
+#pragma unroll
+    for (int a = 0; a < kChunk; ++a) {
+      double m2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < kChunk; ++q) {
+        const double ux = ax_[q] - ax_[a], uy = ay_[q] - ay_[a];
+        m2 = fmax(m2, ux * ux + uy * uy);
+      }
+      if (m2 < adx2) { adx2 = m2; qa = a; }
+    }
+    const double adx = sqrt(adx2);
+    double rot2 = 0.0, acs = ac_[0], asn = as_[0];
+#pragma unroll
+    for (int q = 1; q < kChunk; ++q)
+      if (qa == q) { acs = ac_[q]; asn = as_[q]; }
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) {
+      const double dc = ac_[q] - acs, ds = as_[q] - asn;
       rot2 = fmax(rot2, dc * dc + ds * ds);
     }
+    const int ka = (k0 + qa < k1) ? k0 + qa : k1 - 1;
     ChunkAnchor an;
     an.adx = adx * (1.0 + 1e-9) + 2e-9;    // (+ the absolute allowance of the test: values are compared as computed)
     an.rot2 = rot2 * (1.0 + 1e-8) + 1e-18;
@@ -816,13 +836,17 @@ __device__ __forceinline__ void scan_layer1(const ShapeParams &sp, const Pose *p
           }
           M |= (unsigned long long)Grp<G>::ballot(need) << jb;
         }
-        if (__popcll(M) >= SVSDF_ANCHOR_MIN) {
+        const int ns = __popcll(M);
+        if (ns >= SVSDF_ANCHOR_MIN) {
           // lane li takes the survivor of rank li (ascending list position); survivors beyond the eighth -- rare -- are left
           // to the plain walk below, which resumes behind the eighth one (and tests them against the minimum found by then)
           unsigned long long m = M;
           for (int q = 0; q < li; ++q) m &= m - 1ull;
-          for (int q = 0; q < 8; ++q) M &= M - 1ull;
-          j = M ? (__ffsll((long long)M) - 1) : nl;
+          j = nl;
+          if (ns > 8) {
+            for (int q = 0; q < 8; ++q) M &= M - 1ull;
+            j = __ffsll((long long)M) - 1;
+          }
           bool nf = m != 0ull;
           const int cc = chunk_at(nf ? (__ffsll((long long)m) - 1) : 0);
           double lba = 1e300, da = 1e300;   // lba: lower bound of every pose of chunk cc from its anchor
