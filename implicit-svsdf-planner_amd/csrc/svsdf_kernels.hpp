@@ -453,7 +453,7 @@ __device__ __forceinline__ double sdf_at(const TrajL &tr, const ShapeParams &sp,
 // k_prep: one block.  in = [coeffs (6N x 3 column-major) | T (N) | tk (K)] as uploaded.
 // Also clears the per-batch control blocks for this evaluation.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_prep(const double *__restrict__ in, int N, double dur, int K, int exact,
+__global__ void __launch_bounds__(1024) k_prep(const double *__restrict__ in, int N, double dur, int K, int exact,
                        TrajDev *__restrict__ tr, Pose *__restrict__ pose,
                        Chunk *__restrict__ chunks, double r_bound, BatchCtl *__restrict__ ctl,
                        int nbatch, int *__restrict__ nonfinite) {

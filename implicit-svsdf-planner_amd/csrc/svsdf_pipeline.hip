@@ -465,7 +465,9 @@ int upload_traj(svsdf_ctx *ctx, int N, const double *coeffs, const double *T, bo
   ctx->K = (int)K;
   HIPCHK(hipMemcpyAsync(ctx->d_in, ctx->h_in, need * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const size_t lds = (size_t)traj_lds_doubles(N) * sizeof(double);
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(kBlock), lds, ctx->stream, ctx->d_in, N, dur, (int)K,
+  // one block of 1024 threads (round 6; 256 before): a pose per thread for the ~ 600 poses of a reference-scale trajectory
+  // instead of three one after the other, and four waves per SIMD to hide the chain's latencies behind
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), lds, ctx->stream, ctx->d_in, N, dur, (int)K,
                      ctx->piece_time_mode, ctx->d_traj,
                      ctx->d_pose, ctx->d_chunks, ctx->r_bound, ctx->d_ctl, ctx->nbatch, clear_nonfinite ? ctx->d_nonfinite : nullptr);
   return SVSDF_OK;
