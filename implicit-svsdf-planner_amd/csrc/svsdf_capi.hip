@@ -208,6 +208,7 @@ svsdf_ctx *svsdf_create(const svsdf_config *cfg) {
   if (const char *e = std::getenv("SVSDF_SCAN_ANCHORS")) ctx->scan_anchors = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL_DUO")) ctx->tail_duo = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL_LOCAL")) ctx->tail_local = std::atoi(e) != 0;
+  if (const char *e = std::getenv("SVSDF_TAIL_LATENCY")) ctx->tail_latency = std::atoi(e) != 0;
   if (const char *e = std::getenv("SVSDF_TAIL")) ctx->tail_mode = (std::string(e) == "off") ? -2 : (std::string(e) == "auto") ? -1 : std::max(0, std::atoi(e));
   if (const char *e = std::getenv("SVSDF_UB_FULL")) { ctx->ub_full = std::atoi(e) != 0; ctx->ub_lazy = std::atoi(e) == 2; ctx->ub_anchor = std::atoi(e) == 3; ctx->ub_env = true; }
   if (const char *e = std::getenv("SVSDF_PROFILE")) ctx->profile = std::atoi(e) != 0;

@@ -155,6 +155,7 @@ struct svsdf_ctx {
   int tail_all_after = 1 << 30;          // steps of a point inside k_tail after which every sample is requested (-1: like the chain)
   int tail_iter = -1;                    // this evaluation: iteration the tail starts at (-1: none)
   bool tail_duo = true;                  // k_tail with one point per wave: both half-waves own the point and share its seed scans (env SVSDF_TAIL_DUO=0: off)
+  bool tail_latency = true;              // small launches of k_tail (a wave slot per point at two waves per SIMD) use the instantiation that keeps its ~ 240 VGPRs (env SVSDF_TAIL_LATENCY=0: the 168-VGPR one everywhere; same results)
   bool tail_local = true;                // k_tail from iteration 0 keeps its points' GSIP state and samples in the wave's LDS (env SVSDF_TAIL_LOCAL=0: global arrays)
   long long prev_nactive[svsdf::kMaxIter] = {}; // active GSIP points per iteration of the previous evaluation, up to its tail
   int prev_tail_iter = -1;

@@ -2449,8 +2449,15 @@ __device__ __forceinline__ void tail_solve_pass(const TrajL &tr, const double *_
 #ifndef SVSDF_TAIL_WAVES
 #define SVSDF_TAIL_WAVES 3   // waves per SIMD the register allocation aims at (168 VGPRs)
 #endif
-template <int SHAPE, int MODE>
-__global__ void __launch_bounds__(kTailBlock, SVSDF_TAIL_WAVES)
+// WAVES: waves per SIMD the register allocation aims at.  3 (168 VGPRs) is what a cloud of thousands of points wants -- and
+// costs ~ 100 spilled VGPRs (300 - 400 B of scratch per lane).  A launch with a wave slot for every point at TWO waves per
+// SIMD (<= 2048 points on 256 CUs: the reference's own scale) is a chain of dependent steps of single waves, where a scratch
+// round trip is pure latency: kTailLatencyWaves = 2 lets the kernel keep its ~ 240 VGPRs, no scratch (end of round 6:
+// reference-scale callbacks - 4 ... - 5 %, 3 k-point clouds - 1.5 %; 10 k points + 2 % -- hence two instantiations,
+// chosen per launch: launch_tail).
+constexpr int kTailLatencyWaves = 2;
+template <int SHAPE, int MODE, int WAVES = SVSDF_TAIL_WAVES>
+__global__ void __launch_bounds__(kTailBlock, WAVES)
 k_tail(const TrajDev *__restrict__ trg, const double *__restrict__ tk, const Pose *__restrict__ pose_g,
        const Chunk *__restrict__ chunks_g, ShapeParams sp, const double *__restrict__ px_, const double *__restrict__ py_,
        GsipState gs, size_t stride, int it0, int prev_mode, double delta, double band_delta, int all_after, int ppw,

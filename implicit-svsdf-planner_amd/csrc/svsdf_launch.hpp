@@ -23,10 +23,11 @@ struct RoundLaunch {   // arguments of k_round<SHAPE, LP, MODE>
   size_t stride; int it; double delta, band_delta; double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl;
   int clist_on;   // 1: scans / cheap bounds walk the per-point candidate-chunk list (0: all chunks; same results)
 };
-struct TailLaunch {    // arguments of k_tail<SHAPE, MODE>
+struct TailLaunch {    // arguments of k_tail<SHAPE, MODE, WAVES>
   const TrajDev *traj; const double *tk; const Pose *pose; const Chunk *chunks; ShapeParams sp; const double *px, *py;
   GsipState gs; size_t stride; int it0, prev_mode; double delta, band_delta; int all_after, ppw;
   double *res_sdf, *res_t, *res_gx, *res_gy; BatchCtl *ctl; int clist_on, prune;
+  int latency;   // not a kernel argument: 1 = the instantiation that keeps its registers (kTailLatencyWaves per SIMD, no scratch)
 };
 struct ClassifyLaunch {   // arguments of k_classify<SHAPE>
   const TrajDev *traj; ShapeParams sp; const double *px, *py, *sdf, *t; double *res_sdf, *res_t, *res_gx, *res_gy;

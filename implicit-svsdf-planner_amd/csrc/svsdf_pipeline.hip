@@ -302,7 +302,9 @@ void launch_tail(svsdf_ctx *ctx, hipStream_t st, int b, int it0) {
   const double *d_tk = ctx->d_in + 19 * (size_t)ctx->N;
   const TailLaunch a{ctx->d_traj, d_tk, ctx->d_pose, ctx->d_chunks, ctx->sp, ctx->d_px, ctx->d_py, ctx->gs, ctx->icap, it0, mode,
                      sel, ctx->select_delta, all_after, ppw, ctx->d_res_sdf, ctx->d_res_t, ctx->d_res_gx, ctx->d_res_gy,
-                     ctx->d_ctl + b, ctx->round_list | (local ? 4 : 0) | (ctx->tail_duo ? 0 : 8) | ((ctx->scan_anchors && ctx->lipschitz_ok) ? 16 : 0), ctx->prune};
+                     ctx->d_ctl + b, ctx->round_list | (local ? 4 : 0) | (ctx->tail_duo ? 0 : 8) | ((ctx->scan_anchors && ctx->lipschitz_ok) ? 16 : 0), ctx->prune,
+                     // a wave slot for every point at two waves per SIMD: the instantiation without scratch (k_tail, kTailLatencyWaves)
+                     (ctx->tail_latency && ppw == 1 && pts <= (long long)ctx->n_cu * 4 * svsdf::kTailLatencyWaves) ? 1 : 0};
   size_t e0 = 0, e1 = 0;
   if (ctx->profile) { e0 = next_event(ctx); (void)hipEventRecord(ctx->ev_pool[e0], st); }
   if (!launch_k_tail(poly_lds ? (int)kPolygonLds : ctx->cfg.shape_id, mode, grid, lds, st, a) && ctx->launch_err.empty())

@@ -80,12 +80,14 @@ bool tail_s(int mode, unsigned grid, size_t lds, hipStream_t st, const TailLaunc
   if constexpr (!kernel_shape_enabled<S>()) {
     return false;
   } else {
-#define TAIL(MODE)                                                                                                   \
-  hipLaunchKernelGGL((k_tail<S, MODE>), dim3(grid), dim3(kTailBlock), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp,  \
+#define TAIL_W(MODE, WAVES)                                                                                                 \
+  hipLaunchKernelGGL((k_tail<S, MODE, WAVES>), dim3(grid), dim3(kTailBlock), lds, st, a.traj, a.tk, a.pose, a.chunks, a.sp,  \
                      a.px, a.py, a.gs, a.stride, a.it0, a.prev_mode, a.delta, a.band_delta, a.all_after, a.ppw, a.res_sdf,   \
                      a.res_t, a.res_gx, a.res_gy, a.ctl, a.clist_on, a.prune)
+#define TAIL(MODE) do { if (a.latency) TAIL_W(MODE, kTailLatencyWaves); else TAIL_W(MODE, SVSDF_TAIL_WAVES); } while (0)
     if (mode == 3) TAIL(3); else if (mode == 2) TAIL(2); else if (mode == 1) TAIL(1); else TAIL(0);
 #undef TAIL
+#undef TAIL_W
     return true;
   }
 }
